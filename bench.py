@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on BASELINE config 2 (configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (per rank; SURVEY.md 8d "cfg2"): 4096 stored-block streams + 4096
+fixed-Huffman streams, every stream inflating to one 64 KiB block; streams are
+generated deterministically (tools/streamgen.c, seed 0xDEB16 + global stream index).
+One "step" = one pass of the hot path (the batched inflate kernel through the C-ABI,
+include/debig_hip.h) over the whole batch, inputs already resident in HBM.
+
+  value      decompressed GB/s, whole job  = sum over ranks of D bytes / max-over-ranks time
+  roofline   the dominant kernel launch (fixed-Huffman batch): algorithmic bytes C + D per
+             launch / average launch duration (HIP events on the launch stream)
+  cpu_baseline  the compiled reference (oracle/_ref, single thread) or, if that prebuilt
+             library is absent, the oracle port -- timed on a bounded sample of the same streams
+
+Multi-GPU (--gpus N, launched by torch.distributed.run): one process per GPU; rank 0
+builds the shard map (stream id -> rank, offsets) and broadcasts it over RCCL; every
+rank inflates its own shard; no payload collective (weak scaling: per-GPU work fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is achievable
+STREAMS_PER_KIND = 4096
+STREAM_BYTES = 65536
+
+
+def build_shard_map(world, per_kind):
+    """rank 0's table: global stream id -> (rank, kind, local index).  Round-robin."""
+    total = world * per_kind
+    ids = np.arange(total, dtype=np.int64)
+    return np.stack([ids, ids % world, ids // world], axis=1)  # [id, rank, local]
+
+
+def cpu_baseline(sample_fixed, sample_stored):
+    """Reference (or oracle port) single-thread throughput on a bounded sample."""
+    from oracle import binding
+
+    kind = "port"
+    eng = None
+    if binding.ref_available("A"):
+        try:
+            eng = binding.Reference("A")
+            kind = "reference"
+        except OSError:
+            eng = None
+    if eng is None:
+        eng = binding.Oracle()
+    nbytes = 0
+    t0 = time.perf_counter()
+    for raw, plain in sample_fixed + sample_stored:
+        cap = max(len(plain) + 1, len(raw))
+        out = eng.inflate(raw, cap)
+        assert out[0] == 1 and out[1] == len(plain)
+        nbytes += len(plain)
+    dt = time.perf_counter() - t0
+    return {
+        "value": nbytes / dt / 1e9,
+        "unit": "GB/s decompressed",
+        "cores": 1,
+        "kind": kind,
+        "sample": f"{len(sample_fixed)} fixed-Huffman + {len(sample_stored)} stored streams of 64 KiB "
+                  f"(same generator), 1 thread, {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=STREAMS_PER_KIND, help="streams per kind per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", type=int, default=64, help="streams per kind checked against the generator")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+
+    from debigulator_amd import workload
+    from debigulator_amd.batch import DeviceBatch
+
+    per = args.streams
+    # ---- shard map: rank 0 builds it, RCCL broadcasts it (the only collective on the path)
+    smap = torch.zeros((world * per, 3), dtype=torch.int64, device=dev)
+    if rank == 0:
+        smap.copy_(torch.from_numpy(build_shard_map(world, per)))
+    if world > 1:
+        dist.broadcast(smap, src=0)
+    mine = smap[smap[:, 1] == rank][:, 0].cpu().numpy()  # global stream ids of this rank
+    assert len(mine) == per
+
+    # ---- synthesise this rank's shard (deterministic) and park it in HBM
+    ncpu = max(1, min(16, (os.cpu_count() or 8) // max(1, min(world, 8))))
+    batches = {}
+    pairs_keep = {}
+    for kind in ("stored", "fixed"):
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(ncpu) as ex:
+            pairs = list(ex.map(lambda g: workload.make_stream(kind, int(g), STREAM_BYTES), mine))
+        raws = [p[0] for p in pairs]
+        caps = [max(STREAM_BYTES + 1, len(r)) for r in raws]
+        batches[kind] = DeviceBatch.from_streams(raws, caps, device=dev)
+        batches[kind].c_bytes = sum(len(r) for r in raws)
+        batches[kind].d_bytes = STREAM_BYTES * len(raws)
+        pairs_keep[kind] = pairs[: max(args.verify, 1024)]
+        del pairs
+
+    def step():
+        batches["stored"].launch()
+        batches["fixed"].launch()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # ---- bit-exactness gate (untimed): sample of outputs vs the generator's plain bytes
+    for kind, b in batches.items():
+        res = b.results()
+        assert (res["good"] == 1).all(), f"{kind}: a stream failed"
+        assert (res["final_size"] == STREAM_BYTES).all(), f"{kind}: wrong size"
+        for i, (_, plain) in enumerate(pairs_keep[kind][: args.verify]):
+            assert b.output(i, res) == plain.tobytes(), f"{kind} stream {i} differs"
+
+    # ---- timed region: exactly K steps between barrier+sync on both sides
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        batches["stored"].launch()
+        ev[k][1].record()
+        batches["fixed"].launch()
+        ev[k][2].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+
+    stored_ms = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)]))
+    fixed_ms = float(np.mean([ev[k][1].elapsed_time(ev[k][2]) for k in range(args.steps)]))
+
+    if rank == 0:
+        d_per_rank = sum(b.d_bytes for b in batches.values())
+        value = world * d_per_rank * args.steps / dt_max / 1e9
+        fx, sb = batches["fixed"], batches["stored"]
+        alg_fixed = fx.c_bytes + fx.d_bytes
+        alg_stored = sb.c_bytes + sb.d_bytes
+        ach_fixed = alg_fixed / (fixed_ms * 1e-3) / 1e9
+        ach_stored = alg_stored / (stored_ms * 1e-3) / 1e9
+        res_f = fx.results()
+        line = {
+            "metric": "decompressed GB/s (whole node) + % HBM roofline, bit-exact vs reference",
+            "value": value,
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"cfg2: per GPU {per} stored + {per} fixed-Huffman DEFLATE streams, 64 KiB each "
+                            f"(one 64 KiB block per stream; stored = 65535+1 byte blocks), seed 0xDEB16+i",
+                "streams_per_gpu": 2 * per,
+                "decompressed_bytes_per_gpu": d_per_rank,
+                "compressed_bytes_per_gpu": fx.c_bytes + sb.c_bytes,
+                "sharding": "round-robin by stream id, shard map broadcast over RCCL, no payload collective",
+                "bit_exact_checked": f"{args.verify} streams per kind byte-for-byte + all sizes/good flags",
+            },
+            "variants": {
+                "fixed_huffman": {"decompressed_GBps": fx.d_bytes / (fixed_ms * 1e-3) / 1e9, "kernel_ms": fixed_ms,
+                                  "ratio": fx.d_bytes / fx.c_bytes,
+                                  "avg_spec_rounds_per_window": float(res_f["n_rounds"].sum()) / max(1, float(res_f["n_windows"].sum()))},
+                "stored": {"decompressed_GBps": sb.d_bytes / (stored_ms * 1e-3) / 1e9, "kernel_ms": stored_ms},
+            },
+            "roofline": {
+                "kernel": "debig_inflate_kernel (fixed-Huffman launch: the dominant launch of a step)",
+                "bound": "hbm",
+                "achieved": ach_fixed,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": ach_fixed / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_fixed,
+                "avg_launch_ms": fixed_ms,
+            },
+            "roofline_stored": {
+                "kernel": "debig_inflate_kernel (stored-block launch)",
+                "bound": "hbm",
+                "achieved": ach_stored,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": ach_stored / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_stored,
+                "avg_launch_ms": stored_ms,
+            },
+        }
+        if not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(pairs_keep["fixed"][:1024], pairs_keep["stored"][:1024])
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "GB/s decompressed", "cores": 1, "kind": "port",
+                                        "sample": f"failed: {e}"}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

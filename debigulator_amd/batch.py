@@ -1,0 +1,100 @@
+"""Batched inflate on the GPU: arenas in HBM + one kernel launch.
+
+torch is used for what it is good at here -- device memory and streams; the
+compute is the hand-written HIP kernel behind `debig_hip_inflate_batch`
+(include/debig_hip.h).  Mirrors N calls of the reference's inflate()
+(src/inflate.h:51-60): per stream an input slice, a recipient slice with
+`recipient_size`, and back come `final_recipient_size` and `good`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+STREAM_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u8"), ("out_off", "<u8"), ("out_cap", "<u8"),
+                         ("p2_s0", "<i8"), ("p2_est", "<u8"), ("p2_on", "<u4"), ("reserved", "<u4")])
+RESULT_DTYPE = np.dtype([("final_size", "<u8"), ("good", "<u4"), ("status", "<u4"), ("final_set", "<u4"),
+                         ("n_blocks", "<u4"), ("n_windows", "<u4"), ("n_rounds", "<u4")])
+assert STREAM_DTYPE.itemsize == C.sizeof(N.DebigStream)
+assert RESULT_DTYPE.itemsize == C.sizeof(N.DebigResult)
+
+OUT_SLACK = 64  # bytes between recipients (never written; lets tests verify that)
+
+
+def _align(x, a):
+    return (x + a - 1) // a * a
+
+
+def pack_streams(raws, caps, in_align=16, out_align=16, in_skew=0, out_skew=0, p2=None):
+    """Lay n compressed streams and their recipients out in two arenas (host side).
+
+    Returns (in_arena uint8[], streams structured[], out_bytes)."""
+    n = len(raws)
+    streams = np.zeros(n, dtype=STREAM_DTYPE)
+    in_off = 0
+    out_off = 0
+    for i in range(n):
+        in_off = _align(in_off, in_align) + in_skew
+        out_off = _align(out_off, out_align) + out_skew
+        streams[i]["in_off"] = in_off
+        streams[i]["in_len"] = len(raws[i])
+        streams[i]["out_off"] = out_off
+        streams[i]["out_cap"] = caps[i]
+        if p2 is not None and p2[i] is not None:
+            streams[i]["p2_on"] = 1
+            streams[i]["p2_s0"] = p2[i][0]
+            streams[i]["p2_est"] = p2[i][1]
+        in_off += len(raws[i])
+        out_off += caps[i] + OUT_SLACK
+    in_arena = np.zeros(_align(in_off, 16) + 64, dtype=np.uint8)
+    for i in range(n):
+        o = int(streams[i]["in_off"])
+        in_arena[o:o + len(raws[i])] = np.frombuffer(raws[i], dtype=np.uint8)
+    return in_arena, streams, _align(out_off, 16) + 64
+
+
+class DeviceBatch:
+    """Streams resident in HBM, ready to be inflated any number of times."""
+
+    def __init__(self, in_arena, streams, out_bytes, device="cuda:0"):
+        import torch
+
+        self.torch = torch
+        self.device = torch.device(device)
+        self.n = len(streams)
+        self.streams_host = streams
+        self.d_in = torch.from_numpy(in_arena).to(self.device)
+        self.d_out = torch.zeros(out_bytes, dtype=torch.uint8, device=self.device)
+        self.d_streams = torch.from_numpy(streams.view(np.uint8).reshape(-1)).to(self.device)
+        self.d_results = torch.zeros(self.n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
+        self.lib = N.lib()
+
+    @classmethod
+    def from_streams(cls, raws, caps, device="cuda:0", **kw):
+        in_arena, streams, out_bytes = pack_streams(raws, caps, **kw)
+        return cls(in_arena, streams, out_bytes, device)
+
+    def launch(self, stream=None):
+        """Asynchronous: one kernel launch on `stream` (default: torch's current stream)."""
+        torch = self.torch
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        rc = self.lib.debig_hip_inflate_batch(self.d_in.data_ptr(), self.d_out.data_ptr(),
+                                              self.d_streams.data_ptr(), self.d_results.data_ptr(),
+                                              self.n, C.c_void_p(stream.cuda_stream))
+        N.check(rc, "debig_hip_inflate_batch")
+
+    def results(self):
+        self.torch.cuda.synchronize(self.device)
+        return self.d_results.cpu().numpy().view(RESULT_DTYPE)
+
+    def output(self, i, res=None):
+        res = self.results() if res is None else res
+        o = int(self.streams_host[i]["out_off"])
+        n = int(res[i]["final_size"])
+        return self.d_out[o:o + n].cpu().numpy().tobytes()
+
+    def outputs_host(self):
+        self.torch.cuda.synchronize(self.device)
+        return self.d_out.cpu().numpy()

@@ -1,0 +1,63 @@
+"""Build the native library IN-TREE (debigulator_amd/lib/libdebigulator_hip.so).
+
+    python -m debigulator_amd.build        # or  __graft_entry__.build()
+
+hipcc cross-compiles gfx950 code objects without a GPU.  The host-side C sources
+(the drop-in inflate/decode_png/decode_gz layer) are compiled as C by the same
+driver and linked into the one shared library.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libdebigulator_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra_defs=()):
+    os.makedirs(LIBDIR, exist_ok=True)
+    root = os.path.dirname(HERE)
+    deps = (glob.glob(os.path.join(CSRC, "*")) + glob.glob(os.path.join(CSRC, "host", "*")) +
+            glob.glob(os.path.join(root, "include", "*.h")))
+    if not force and not extra_defs and not _newer(LIB, deps):
+        return LIB
+    objs = []
+    odir = os.path.join(LIBDIR, "obj")
+    os.makedirs(odir, exist_ok=True)
+    inc = ["-I" + os.path.join(root, "include")]
+    defs = ["-D" + d for d in extra_defs]
+    for c in sorted(glob.glob(os.path.join(CSRC, "host", "*.c"))):
+        o = os.path.join(odir, os.path.basename(c) + ".o")
+        cmd = ["gcc", "-O2", "-fPIC", "-std=c11", "-Wall", "-Wextra", "-fvisibility=hidden"] + inc + ["-c", c, "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(o)
+    o = os.path.join(odir, "debig_hip.o")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + inc + defs + [
+        "-c", os.path.join(CSRC, "debig_hip.hip"), "-o", o]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    objs.append(o)
+    # -Bsymbolic: our internal calls must never bind to zlib's `inflate`
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

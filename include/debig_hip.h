@@ -1,0 +1,110 @@
+/*
+ * debig_hip.h -- C-ABI of libdebigulator_hip.so: the MI355X (gfx950) batched
+ * DEFLATE inflate / PNG de-filter path behind debigulator's header API.
+ *
+ * Everything here is plain C: pointers, sizes, POD structs.  No HIP or torch
+ * types appear in a signature; `hip_stream` is an opaque hipStream_t passed as
+ * void* (NULL = the default stream).
+ *
+ * What each entry point replaces in the reference (ArtOfBBQ/debigulator):
+ *   debig_hip_inflate_batch     N x inflate()            src/inflate.h:51-60, src/inflate.c:786-1965
+ *   debig_hip_png_defilter_batch the de-filter + palette loops of decode_png()
+ *                                                         src/decode_png.c:1381-1564
+ * The single-call drop-in API (inflate / decode_png / decode_gz with the
+ * reference's own prototypes) is in inflate.h, decode_png.h, decode_gz.h next to
+ * this file and is implemented on top of these batch calls.
+ */
+#ifndef DEBIG_HIP_H
+#define DEBIG_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One raw DEFLATE stream (what one reference inflate() call receives).  Offsets
+ * are relative to the input / output arenas given to the batch call. */
+typedef struct debig_stream {
+    uint64_t in_off;  /* first byte of the compressed stream (any alignment)          */
+    uint64_t in_len;  /* compressed_input_size (reference inflate.h:57)               */
+    uint64_t out_off; /* start of the recipient (any alignment)                       */
+    uint64_t out_cap; /* recipient_size (reference inflate.h:52); never written past  */
+    /* decode_png() buffer-aliasing replay (reference quirk):
+     * stream byte index aliased by the first scratch-table byte, and the
+     * recipient size `est`.  p2_on = 0 for plain inflate()/decode_gz().          */
+    int64_t p2_s0;
+    uint64_t p2_est;
+    uint32_t p2_on;
+    uint32_t reserved;
+} debig_stream;
+
+/* status codes in debig_result.status (0 = success) */
+enum {
+    DEBIG_OK = 0,
+    DEBIG_E_GATE_RECIPIENT_SMALL = 1, /* recipient_size < compressed_input_size (inflate.c:826) */
+    DEBIG_E_GATE_INPUT_SHORT = 2,     /* compressed_input_size < 5 (inflate.c:836)              */
+    DEBIG_E_STORED_NLEN = 3,          /* LEN != ~NLEN (inflate.c:949)                           */
+    DEBIG_E_BAD_CODE_LENGTHS = 4,     /* code length >= table size (inflate.c:599)             */
+    DEBIG_E_NO_CODE = 5,              /* bit pattern matches no code (inflate.c:465-473)        */
+    DEBIG_E_DIST_SYMBOL = 6,          /* distance symbol > 29 (inflate.c:1809)                  */
+    DEBIG_E_DIST_TOO_FAR = 7,         /* distance beyond start of output (inflate.c:1843)       */
+    DEBIG_E_OUTPUT_FULL = 8,          /* output would exceed recipient_size (ref: overflow/assert) */
+    DEBIG_E_LITLEN_286_287 = 9        /* symbols 286/287 (ref: reads past its table)            */
+};
+
+typedef struct debig_result {
+    uint64_t final_size; /* *final_recipient_size                                     */
+    uint32_t good;       /* *out_good                                                 */
+    uint32_t status;     /* DEBIG_E_* reason when good == 0                           */
+    uint32_t final_set;  /* 0 when the reference leaves *final_recipient_size untouched */
+    uint32_t n_blocks;
+    uint32_t n_windows;  /* decode windows processed (perf counters, not API)          */
+    uint32_t n_rounds;   /* speculative rounds summed over windows                     */
+} debig_result;
+
+/* Inflate n independent raw DEFLATE streams.  All pointers are DEVICE pointers
+ * (streams/results included); the call is asynchronous on hip_stream.
+ * Returns 0 or a hipError_t value. */
+int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d_streams,
+                            debig_result *d_results, uint32_t n, void *hip_stream);
+
+/* One image for the de-filter kernel: the inflated scanline stream (filter byte
+ * + w*bpp bytes per row) -> 4-channel RGBA. */
+typedef struct debig_png_image {
+    uint64_t stream_off; /* inflated stream, relative to d_streams_arena               */
+    uint64_t rgba_off;   /* output, relative to d_rgba_arena; 4*w*h bytes              */
+    uint64_t pal_off;    /* colour type 3: 768 bytes R[256] G[256] B[256], rel. to d_streams_arena */
+    uint32_t width, height;
+    uint32_t color_type; /* 6 (RGBA), 3 (palette), 2 (RGB, spec-conforming expansion)   */
+    uint32_t asserts_off;/* 0: a filter byte > 4 fails the image (reference default build) */
+} debig_png_image;
+
+typedef struct debig_png_result {
+    uint32_t good;
+    uint32_t bad_row; /* first row whose filter byte was > 4 (when good == 0) */
+} debig_png_result;
+
+int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena,
+                                 const debig_png_image *d_images, debig_png_result *d_results,
+                                 uint32_t n, void *hip_stream);
+
+/* plain device-to-device helpers used by the host layer (no torch needed) */
+int debig_hip_device_count(void);
+int debig_hip_set_device(int dev);
+void *debig_hip_malloc(uint64_t bytes);
+void debig_hip_free(void *p);
+int debig_hip_memcpy_h2d(void *d, const void *h, uint64_t bytes, void *hip_stream);
+int debig_hip_memcpy_d2h(void *h, const void *d, uint64_t bytes, void *hip_stream);
+int debig_hip_memset(void *d, int v, uint64_t bytes, void *hip_stream);
+int debig_hip_stream_sync(void *hip_stream);
+const char *debig_hip_error_string(int err);
+/* kernel timing on the stream the kernels run on (hipEvent based) */
+void *debig_hip_event_create(void);
+int debig_hip_event_record(void *ev, void *hip_stream);
+float debig_hip_event_elapsed_ms(void *start, void *stop); /* synchronises on stop */
+void debig_hip_event_destroy(void *ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,72 @@
+"""TEST TOOLING: run the product's HIP kernels on the CPU lock-step emulator
+(tools/simt_emu).  Same structs as include/debig_hip.h."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tools", "simt_emu")
+
+
+class DebigStream(C.Structure):
+    _fields_ = [("in_off", C.c_uint64), ("in_len", C.c_uint64), ("out_off", C.c_uint64),
+                ("out_cap", C.c_uint64), ("p2_s0", C.c_int64), ("p2_est", C.c_uint64),
+                ("p2_on", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class DebigResult(C.Structure):
+    _fields_ = [("final_size", C.c_uint64), ("good", C.c_uint32), ("status", C.c_uint32),
+                ("final_set", C.c_uint32), ("n_blocks", C.c_uint32), ("n_windows", C.c_uint32),
+                ("n_rounds", C.c_uint32)]
+
+
+def load_emu(asan=False):
+    name = "libdebig_emu_asan.so" if asan else "libdebig_emu.so"
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, name])
+    L = C.CDLL(os.path.join(EMU_DIR, name))
+    L.emu_inflate_batch.restype = C.c_int
+    L.emu_inflate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    return L
+
+
+def layout_batch(raws, caps, in_misalign=0, out_misalign=0, p2=None):
+    """Pack streams into arenas.  Returns (in_arena, out_arena, streams[], results[])."""
+    n = len(raws)
+    streams = (DebigStream * n)()
+    results = (DebigResult * n)()
+    in_off = 64 + in_misalign
+    out_off = 64 + out_misalign
+    offs = []
+    for i, (r, cap) in enumerate(zip(raws, caps)):
+        streams[i].in_off = in_off
+        streams[i].in_len = len(r)
+        streams[i].out_off = out_off
+        streams[i].out_cap = cap
+        if p2 is not None and p2[i] is not None:
+            streams[i].p2_on = 1
+            streams[i].p2_s0 = p2[i][0]
+            streams[i].p2_est = p2[i][1]
+        offs.append((in_off, out_off))
+        in_off += (len(r) + 63 + 16) // 16 * 16 + in_misalign
+        out_off += (cap + 1024 + 15) // 16 * 16 + out_misalign
+    in_arena = np.zeros(in_off + 64, dtype=np.uint8)
+    out_arena = np.full(out_off + 64, 0xA5, dtype=np.uint8)
+    for (io, _), r in zip(offs, raws):
+        in_arena[io:io + len(r)] = np.frombuffer(r, dtype=np.uint8)
+        # poison what follows the stream: the kernel must read it as zero
+        in_arena[io + len(r):io + len(r) + 8] = 0xFF
+    return in_arena, out_arena, streams, results, offs
+
+
+def emu_inflate(L, raws, caps, grid=0, **kw):
+    in_arena, out_arena, streams, results, offs = layout_batch(raws, caps, **kw)
+    rc = L.emu_inflate_batch(in_arena.ctypes.data, out_arena.ctypes.data, streams, results, len(raws), grid)
+    assert rc == 0
+    outs = []
+    for i, (_, oo) in enumerate(offs):
+        r = results[i]
+        final = r.final_size if r.final_set else None
+        outs.append((r.good, final, out_arena[oo:oo + (final or 0)].tobytes(), r))
+    return outs, out_arena, offs

@@ -1,0 +1,14 @@
+/* DEVELOPMENT / TEST TOOLING: the product's HIP kernels compiled for the CPU lock-step
+ * emulator (hip_emu.h).  Exposes the same batch entry points as libdebigulator_hip.so
+ * (include/debig_hip.h) with an emu_ prefix and HOST pointers. */
+#include "hip_emu.h"
+#include "../../include/debig_hip.h"
+#include "../../debigulator_amd/csrc/inflate_kernel.inc"
+
+extern "C" int emu_inflate_batch(const void *in, void *out, const debig_stream *streams,
+                                 debig_result *results, uint32_t n, uint32_t grid)
+{
+    if (grid == 0 || grid > n) grid = n;
+    EMU_LAUNCH(debig_inflate_kernel, grid, 64, (const uint8_t *)in, (uint8_t *)out, streams, results, n);
+    return 0;
+}
