@@ -40,6 +40,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # In a python process torch must come first: it ships its own libamdhip64/libhsa-runtime64
+    # (same soname as /opt/rocm's).  Loaded second, our library binds to torch's copy and both
+    # share one HIP runtime (streams, device pointers); loaded first, it would pull in a second
+    # runtime and torch.cuda would then see no device.  C callers just link /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: run `python -m debigulator_amd.build` (there is no CPU fallback)")
