@@ -19,7 +19,7 @@ class DebigStream(C.Structure):
 class DebigResult(C.Structure):
     _fields_ = [("final_size", C.c_uint64), ("good", C.c_uint32), ("status", C.c_uint32),
                 ("final_set", C.c_uint32), ("n_blocks", C.c_uint32), ("n_windows", C.c_uint32),
-                ("n_rounds", C.c_uint32)]
+                ("n_rounds", C.c_uint32), ("prof", C.c_uint32 * 8)]
 
 
 class DebigPngImage(C.Structure):
@@ -48,10 +48,11 @@ def lib():
         import torch  # noqa: F401
     except ImportError:
         pass
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("DEBIG_LIB", LIB_PATH)  # diagnostic builds (tools/prof_phases.py)
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: run `python -m debigulator_amd.build` (there is no CPU fallback)")
-    L = C.CDLL(LIB_PATH)
+            f"{path} is missing: run `python -m debigulator_amd.build` (there is no CPU fallback)")
+    L = C.CDLL(path)
     vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
     L.debig_hip_inflate_batch.restype = C.c_int
     L.debig_hip_inflate_batch.argtypes = [vp, vp, vp, vp, u32, vp]

@@ -15,7 +15,7 @@ from . import _native as N
 STREAM_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u8"), ("out_off", "<u8"), ("out_cap", "<u8"),
                          ("p2_s0", "<i8"), ("p2_est", "<u8"), ("p2_on", "<u4"), ("reserved", "<u4")])
 RESULT_DTYPE = np.dtype([("final_size", "<u8"), ("good", "<u4"), ("status", "<u4"), ("final_set", "<u4"),
-                         ("n_blocks", "<u4"), ("n_windows", "<u4"), ("n_rounds", "<u4")])
+                         ("n_blocks", "<u4"), ("n_windows", "<u4"), ("n_rounds", "<u4"), ("prof", "<u4", (8,))])
 assert STREAM_DTYPE.itemsize == C.sizeof(N.DebigStream)
 assert RESULT_DTYPE.itemsize == C.sizeof(N.DebigResult)
 

@@ -25,13 +25,15 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra_defs=()):
+def build(force=False, verbose=False, extra_defs=(), out=None):
+    """out: alternative library name (diagnostic builds, e.g. -DDEBIG_PROFILE)"""
     os.makedirs(LIBDIR, exist_ok=True)
+    target = LIB if out is None else os.path.join(LIBDIR, out)
     root = os.path.dirname(HERE)
     deps = (glob.glob(os.path.join(CSRC, "*")) + glob.glob(os.path.join(CSRC, "host", "*")) +
             glob.glob(os.path.join(root, "include", "*.h")))
-    if not force and not extra_defs and not _newer(LIB, deps):
-        return LIB
+    if not force and not _newer(target, deps):
+        return target
     objs = []
     odir = os.path.join(LIBDIR, "obj")
     os.makedirs(odir, exist_ok=True)
@@ -44,7 +46,7 @@ def build(force=False, verbose=False, extra_defs=()):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(o)
-    o = os.path.join(odir, "debig_hip.o")
+    o = os.path.join(odir, "debig_hip" + ("" if out is None else "_" + out) + ".o")
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + inc + defs + [
         "-c", os.path.join(CSRC, "debig_hip.hip"), "-o", o]
     if verbose:
@@ -52,11 +54,11 @@ def build(force=False, verbose=False, extra_defs=()):
     subprocess.check_call(cmd)
     objs.append(o)
     # -Bsymbolic: our internal calls must never bind to zlib's `inflate`
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIB] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", target] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return target
 
 
 if __name__ == "__main__":

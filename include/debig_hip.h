@@ -60,6 +60,10 @@ typedef struct debig_result {
     uint32_t n_blocks;
     uint32_t n_windows;  /* decode windows processed (perf counters, not API)          */
     uint32_t n_rounds;   /* speculative rounds summed over windows                     */
+    /* shader-clock cycles per phase, only filled by -DDEBIG_PROFILE builds (else 0):
+     * 0 stage input, 1 pass-1 scan rounds, 2 pass-2 decode, 3 LZ77 resolve, 4 flush,
+     * 5 headers + tables, 6 whole stream, 7 reserved */
+    uint32_t prof[8];
 } debig_result;
 
 /* Inflate n independent raw DEFLATE streams.  All pointers are DEVICE pointers

@@ -19,7 +19,7 @@ class DebigStream(C.Structure):
 class DebigResult(C.Structure):
     _fields_ = [("final_size", C.c_uint64), ("good", C.c_uint32), ("status", C.c_uint32),
                 ("final_set", C.c_uint32), ("n_blocks", C.c_uint32), ("n_windows", C.c_uint32),
-                ("n_rounds", C.c_uint32)]
+                ("n_rounds", C.c_uint32), ("prof", C.c_uint32 * 8)]
 
 
 def load_emu(asan=False):

@@ -183,6 +183,7 @@ static inline unsigned __brev(unsigned v)
 static inline int emu_readfirstlane(int v) { return emu___shfl(v, 0); }
 
 template <typename T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
+template <typename T> static inline T atomicAnd(T *p, T v) { T o = *p; *p = o & v; return o; }
 template <typename T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> static inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <typename T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
