@@ -20,15 +20,33 @@ static inline uint32_t pick_grid(uint32_t n, uint32_t per_cu)
     return n < cap ? n : cap;
 }
 
+// BTYPE 1 tables, built once per device by a tiny kernel and then only copied into LDS
+static CodeTabs *g_fixed_tabs[64];
+static CodeTabs *fixed_tables(hipStream_t s)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (g_fixed_tabs[dev]) return g_fixed_tabs[dev];
+    CodeTabs *p = nullptr;
+    if (hipMalloc(&p, sizeof(CodeTabs)) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(debig_fixed_tables_kernel, dim3(1), dim3(64), 0, s, p);
+    // later launches may use other streams: make the tables globally visible first
+    if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+    g_fixed_tabs[dev] = p;
+    return p;
+}
+
 extern "C" {
 
 int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d_streams,
                             debig_result *d_results, uint32_t n, void *hip_stream)
 {
     if (n == 0) return 0;
+    CodeTabs *ft = fixed_tables((hipStream_t)hip_stream);
+    if (!ft) return (int)hipErrorOutOfMemory;
     uint32_t grid = n; /* one workgroup per stream: the hardware scheduler balances lengths */
     hipLaunchKernelGGL(debig_inflate_kernel, dim3(grid), dim3(64), 0, (hipStream_t)hip_stream,
-                       (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, d_results, n);
+                       (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, d_results, n, ft);
     return (int)hipGetLastError();
 }
 

@@ -9,6 +9,11 @@ extern "C" int emu_inflate_batch(const void *in, void *out, const debig_stream *
                                  debig_result *results, uint32_t n, uint32_t grid)
 {
     if (grid == 0 || grid > n) grid = n;
-    EMU_LAUNCH(debig_inflate_kernel, grid, 64, (const uint8_t *)in, (uint8_t *)out, streams, results, n);
+    static CodeTabs *ft = nullptr;
+    if (!ft) {
+        ft = (CodeTabs *)calloc(1, sizeof(CodeTabs));
+        EMU_LAUNCH(debig_fixed_tables_kernel, 1, 64, ft);
+    }
+    EMU_LAUNCH(debig_inflate_kernel, grid, 64, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft);
     return 0;
 }
