@@ -1,0 +1,341 @@
+/*
+ * Drop-in decode_png_init / decode_png_deinit / decode_png_get_width_height / decode_png
+ * (reference src/decode_png.h:43-103, src/decode_png.c:562-1567) and their legacy names.
+ *
+ * Host side (plain C): signature, chunk walk, CRC-32, IHDR/PLTE/IDAT validation and IDAT
+ * concatenation follow the reference's accept/reject rules; the two hot loops -- inflate
+ * (src/inflate.c) and the per-byte de-filter / palette loops (src/decode_png.c:1381-1564) --
+ * run on the GPU through debig_hip_inflate_batch / debig_hip_png_defilter_batch.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "decode_png.h"
+#include "debig_ctx.h"
+
+#define INFLATE_HASHMAPS_SIZE 3000000u /* reference src/decode_png.c:16 */
+
+typedef struct png_state {
+    uint8_t palette[768]; /* R[256] G[256] B[256]; persists between calls like the reference's */
+    uint32_t palette_size;
+    uint32_t wm_size;
+    int initialized;
+    void *(*malloc_fn)(uint64_t);
+    void (*free_fn)(void *);
+} png_state;
+
+static png_state g_png[DEBIG_MAX_THREADS];
+
+static uint32_t g_crc_table[256];
+static int g_crc_ready;
+static void crc_init(void)
+{
+    for (uint32_t n = 0; n < 256; n++) {
+        uint32_t c = n;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+        g_crc_table[n] = c;
+    }
+    g_crc_ready = 1;
+}
+static uint32_t crc_update(uint32_t crc, const uint8_t *p, uint64_t n)
+{
+    if (!g_crc_ready) crc_init();
+    for (uint64_t i = 0; i < n; i++) crc = g_crc_table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+    return crc;
+}
+static uint32_t be32(const uint8_t *p)
+{
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+}
+
+DEBIG_API void decode_png_init(void *(*malloc_funcptr)(uint64_t), void (*arg_free_funcptr)(void *),
+                               void *(*arg_memset_funcptr)(void *, int, uint64_t),
+                               void *(*arg_memcpy_func)(void *, const void *, uint64_t),
+                               const uint32_t dpng_working_memory_size, const uint32_t thread_id)
+{
+    if (thread_id >= DEBIG_MAX_THREADS) return;
+    png_state *s = &g_png[thread_id];
+    if (s->initialized) return; /* reference: second init of a thread id is ignored (:580-593) */
+    memset(s, 0, sizeof *s);
+    s->malloc_fn = malloc_funcptr;
+    s->free_fn = arg_free_funcptr;
+    s->wm_size = dpng_working_memory_size; /* only its size matters: no host scratch is needed */
+    s->initialized = 1;
+    inflate_init(malloc_funcptr, arg_memset_funcptr, arg_memcpy_func, thread_id);
+}
+
+DEBIG_API void decode_png_deinit(const uint32_t thread_id)
+{
+    if (thread_id >= DEBIG_MAX_THREADS) return;
+    g_png[thread_id].initialized = 0;
+    debig_ctx_release(thread_id);
+}
+
+DEBIG_API void decode_png_get_width_height(const uint8_t *in, const uint64_t in_size, uint32_t *w,
+                                           uint32_t *h, uint8_t *good)
+{ /* src/decode_png.c:620-681: needs 28 bytes, only checks "PNG" */
+    *w = 0;
+    *h = 0;
+    *good = 0;
+    if (in == NULL || in_size < 28) return;
+    if (in[1] != 'P' || in[2] != 'N' || in[3] != 'G') return;
+    *w = be32(in + 16);
+    *h = be32(in + 20);
+    *good = 1;
+}
+
+/* result of the host-side container walk for one file */
+typedef struct png_parsed {
+    int ok;            /* container accepted; inflate + de-filter still to run */
+    uint32_t w, h, ct;
+    uint64_t est;      /* recipient_size the reference hands to inflate: 4wh + h + 1 */
+    uint8_t *zdata;    /* concatenated IDAT payload minus the 2-byte zlib header (malloc'd) */
+    uint64_t zsize;    /* compressed_input_size handed to inflate (payload - 4 Adler bytes) */
+} png_parsed;
+
+/* The container walk restated (src/decode_png.c:730-1367): returns ok = 0 wherever the
+ * reference sets *out_good = 0 before inflate runs.  size_left bookkeeping mirrors the
+ * reference's (it does not subtract the IHDR / PLTE bodies or the zlib header). */
+static void png_walk(png_state *st, const uint8_t *in, uint64_t in_size, uint64_t rgba_size, png_parsed *r)
+{
+    memset(r, 0, sizeof *r);
+    if (in == NULL || in_size < 8) return;
+    if (in[1] != 'P' || in[2] != 'N' || in[3] != 'G') return;
+    uint64_t at = 8, left = in_size - 8, packed = 0;
+    int found_ihdr = 0, found_idat = 0, found_iend = 0, ready = 0;
+    uint8_t *z = (uint8_t *)malloc(in_size + 16);
+    if (!z) return;
+    while (left >= 8 && !found_iend) {
+        if (at + 8 > in_size) goto fail;
+        uint32_t len = be32(in + at);
+        const uint8_t *type = in + at + 4;
+        at += 8;
+        left -= 8;
+        int is_idat = !memcmp(type, "IDAT", 4);
+        if (!is_idat && found_idat) ready = 1; /* the reference runs inflate here (:775-860) */
+        if ((uint64_t)len >= left || at + (uint64_t)len + 4 > in_size) goto fail; /* :886-898 */
+        uint32_t crc = crc_update(0xffffffffu, type, 4);
+        if (len) crc = crc_update(crc, in + at, len);
+        crc ^= 0xffffffffu;
+        if (!memcmp(type, "PLTE", 4)) { /* :900-950 */
+            if (!found_ihdr) goto fail;
+            if (r->ct == 0) goto fail;
+            if (len % 3 != 0) goto fail;
+            st->palette_size = len / 3;
+            for (uint32_t i = 0; i < st->palette_size; i++) {
+                if (i < 256) {
+                    st->palette[i] = in[at];
+                    st->palette[256 + i] = in[at + 1];
+                    st->palette[512 + i] = in[at + 2];
+                }
+                at += 3;
+            }
+        } else if (!memcmp(type, "IHDR", 4)) { /* :951-1138 */
+            found_ihdr = 1;
+            if (at + 13 > in_size) goto fail;
+            r->w = be32(in + at);
+            r->h = be32(in + at + 4);
+            uint8_t depth = in[at + 8];
+            r->ct = in[at + 9];
+            uint8_t filter_method = in[at + 11];
+            at += 13;
+            r->est = (uint64_t)(uint32_t)(r->w * r->h * 4u + r->h + 1u);
+            if ((uint64_t)(uint32_t)(r->w * r->h * 4u) != rgba_size) goto fail;
+            if (r->ct != 2 && r->ct != 3 && r->ct != 6) goto fail;
+            if (r->w < 1 || r->h < 1) goto fail;
+            if ((uint64_t)(uint32_t)(r->w * r->h * 4u + r->h + 1u + INFLATE_HASHMAPS_SIZE) > st->wm_size) goto fail;
+            if (depth != 8) goto fail;
+            if (filter_method != 0) goto fail;
+            if (left < 4) goto fail;
+        } else if (is_idat) { /* :1139-1292 */
+            if (!found_ihdr) goto fail;
+            uint32_t dlen = len;
+            if (!found_idat) {
+                found_idat = 1;
+                if (at + 2 > in_size) goto fail;
+                uint8_t cmf = in[at], flg = in[at + 1];
+                at += 2;
+                dlen -= 2;
+                if ((cmf & 15u) != 8) goto fail;
+                uint32_t chk = (uint16_t)(flg | (uint16_t)(cmf << 8));
+                if (chk == 0 || chk % 31u != 0) goto fail;
+                if ((flg >> 5) & 1u) goto fail; /* FDICT */
+            }
+            if (at + (uint64_t)dlen > in_size) goto fail;
+            memcpy(z + packed, in + at, dlen);
+            packed += dlen;
+            at += dlen;
+            left -= dlen;
+        } else if (!memcmp(type, "IEND", 4)) {
+            found_iend = 1;
+        } else if ((char)type[0] > 'Z') {
+            at += len;
+            left -= len;
+        } else {
+            goto fail; /* unknown critical chunk */
+        }
+        if (left < 4 || at + 4 > in_size) goto fail;
+        uint32_t file_crc = be32(in + at);
+        at += 4;
+        left -= 4;
+        if (crc != file_crc) goto fail;
+    }
+    if (!ready) goto fail; /* P6: inflate only runs when a non-IDAT chunk follows the IDATs */
+    r->zdata = z;
+    r->zsize = (uint64_t)(uint32_t)((uint32_t)packed - 4u); /* uint32 arithmetic as in :816 */
+    r->ok = 1;
+    return;
+fail:
+    free(z);
+    r->ok = 0;
+}
+
+static int strict_mode(void)
+{
+    const char *e = getenv("DEBIG_STRICT");
+    return e && e[0] == '1';
+}
+
+DEBIG_API int debig_decode_png_batch(const uint8_t *const *inputs, const uint64_t *input_sizes,
+                                     uint8_t *const *outs, const uint64_t *out_sizes, uint8_t *goods,
+                                     uint32_t n, const uint32_t thread_id)
+{
+    for (uint32_t i = 0; i < n; i++) goods[i] = 0;
+    if (thread_id >= DEBIG_MAX_THREADS || !g_png[thread_id].initialized) return 0; /* :691-700 */
+    png_state *st = &g_png[thread_id];
+    debig_ctx *c = debig_ctx_get(thread_id);
+    if (n == 0) return 0;
+    png_parsed *P = (png_parsed *)calloc(n, sizeof(png_parsed));
+    debig_stream *desc = (debig_stream *)calloc(n, sizeof(debig_stream));
+    debig_result *res = (debig_result *)calloc(n, sizeof(debig_result));
+    debig_png_image *img = (debig_png_image *)calloc(n, sizeof(debig_png_image));
+    debig_png_result *ires = (debig_png_result *)calloc(n, sizeof(debig_png_result));
+    uint8_t *pals = (uint8_t *)calloc(n, 768);
+    int rc = 2;
+    if (!P || !desc || !res || !img || !ires || !pals) goto done;
+    rc = 0;
+    const int strict = strict_mode();
+    uint64_t in_total = 0, out_total = 0, rgba_total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        png_walk(st, inputs[i], input_sizes[i], out_sizes[i], &P[i]);
+        /* palettes are per-thread state in the reference: snapshot what this file sees */
+        memcpy(pals + 768u * i, st->palette, 768);
+        desc[i].in_off = in_total;
+        desc[i].out_off = out_total;
+        if (P[i].ok) {
+            desc[i].in_len = P[i].zsize;
+            desc[i].out_cap = P[i].est;
+            /* P2: recipient = wm + 772, scratch = wm + est; the first
+             * table sits at the first 16-aligned scratch byte (wm itself 16-aligned) */
+            desc[i].p2_on = strict ? 0u : 1u;
+            desc[i].p2_est = P[i].est;
+            desc[i].p2_s0 = (int64_t)P[i].est - 772 + (int64_t)((16u - (P[i].est & 15u)) & 15u);
+            in_total += debig_align16(P[i].zsize) + 16;
+            out_total += debig_align16(P[i].est) + 16 + 768; /* + room for the palette */
+            rgba_total += debig_align16(out_sizes[i]) + 16;
+        }
+    }
+    if ((rc = debig_devbuf_reserve(&c->in, in_total + 64)) || (rc = debig_devbuf_reserve(&c->out, out_total + 64)) ||
+        (rc = debig_devbuf_reserve(&c->rgba, rgba_total + 64)) ||
+        (rc = debig_devbuf_reserve(&c->desc, (uint64_t)n * sizeof(debig_stream))) ||
+        (rc = debig_devbuf_reserve(&c->res, (uint64_t)n * sizeof(debig_result))) ||
+        (rc = debig_devbuf_reserve(&c->img, (uint64_t)n * sizeof(debig_png_image))) ||
+        (rc = debig_devbuf_reserve(&c->imgres, (uint64_t)n * sizeof(debig_png_result))))
+        goto done;
+    for (uint32_t i = 0; i < n && !rc; i++) {
+        if (!P[i].ok || P[i].est < P[i].zsize || P[i].zsize < 5) continue; /* gated streams are never read */
+        rc = debig_hip_memcpy_h2d((uint8_t *)c->in.ptr + desc[i].in_off, P[i].zdata, P[i].zsize, NULL);
+    }
+    if (rc) goto done;
+    if ((rc = debig_hip_memcpy_h2d(c->desc.ptr, desc, (uint64_t)n * sizeof(debig_stream), NULL))) goto done;
+    if ((rc = debig_hip_inflate_batch(c->in.ptr, c->out.ptr, (const debig_stream *)c->desc.ptr,
+                                      (debig_result *)c->res.ptr, n, NULL)))
+        goto done;
+    if ((rc = debig_hip_memcpy_d2h(res, c->res.ptr, (uint64_t)n * sizeof(debig_result), NULL))) goto done;
+    if ((rc = debig_hip_stream_sync(NULL))) goto done;
+    /* de-filter the images whose stream inflated (the first filter byte is checked on the
+     * device together with every other row's; the reference checks it first, :847-858) */
+    uint32_t nimg = 0;
+    uint32_t *map = (uint32_t *)calloc(n, sizeof(uint32_t));
+    if (!map) { rc = 2; goto done; }
+    uint64_t rgba_off = 0;
+    for (uint32_t i = 0; i < n && !rc; i++) {
+        if (!P[i].ok || !res[i].good) continue;
+        debig_png_image *im = &img[nimg];
+        im->stream_off = desc[i].out_off;
+        im->rgba_off = rgba_off;
+        im->pal_off = desc[i].out_off + debig_align16(P[i].est) + 16;
+        im->width = P[i].w;
+        im->height = P[i].h;
+        im->color_type = P[i].ct;
+        im->asserts_off = 0;
+        if (P[i].ct == 3) rc = debig_hip_memcpy_h2d((uint8_t *)c->out.ptr + im->pal_off, pals + 768u * i, 768, NULL);
+        rgba_off += debig_align16(out_sizes[i]) + 16;
+        map[nimg++] = i;
+    }
+    if (!rc && nimg) {
+        rc = debig_hip_memcpy_h2d(c->img.ptr, img, (uint64_t)nimg * sizeof(debig_png_image), NULL);
+        if (!rc)
+            rc = debig_hip_png_defilter_batch(c->out.ptr, c->rgba.ptr, (const debig_png_image *)c->img.ptr,
+                                              (debig_png_result *)c->imgres.ptr, nimg, NULL);
+        if (!rc) rc = debig_hip_memcpy_d2h(ires, c->imgres.ptr, (uint64_t)nimg * sizeof(debig_png_result), NULL);
+        if (!rc) rc = debig_hip_stream_sync(NULL);
+        for (uint32_t k = 0; k < nimg && !rc; k++) {
+            uint32_t i = map[k];
+            if (!ires[k].good) continue;
+            rc = debig_hip_memcpy_d2h(outs[i], (uint8_t *)c->rgba.ptr + img[k].rgba_off, out_sizes[i], NULL);
+            goods[i] = 1;
+        }
+        if (!rc) rc = debig_hip_stream_sync(NULL);
+    }
+    free(map);
+done:
+    if (rc)
+        for (uint32_t i = 0; i < n; i++) goods[i] = 0;
+    if (P)
+        for (uint32_t i = 0; i < n; i++) free(P[i].zdata);
+    free(P);
+    free(desc);
+    free(res);
+    free(img);
+    free(ires);
+    free(pals);
+    return rc;
+}
+
+DEBIG_API void decode_png(const uint8_t *compressed_input, const uint64_t compressed_input_size,
+                          const uint8_t *out_rgba_values, const uint64_t rgba_values_size,
+                          const uint32_t thread_id, uint8_t *out_good)
+{
+    uint8_t good = 0;
+    uint8_t *out = (uint8_t *)out_rgba_values;
+    const uint8_t *in = compressed_input;
+    *out_good = 0;
+    if (!out || !in) return;
+    debig_decode_png_batch(&in, &compressed_input_size, &out, &rgba_values_size, &good, 1, thread_id);
+    *out_good = good;
+}
+
+/* ---- legacy generation (src/hellopng.c:154-200; thread_id 0, good is a uint32_t there) */
+static void *legacy_malloc64(uint64_t n) { return malloc((size_t)n); }
+static void *legacy_memset64(void *p, int c, uint64_t n) { return memset(p, c, (size_t)n); }
+static void *legacy_memcpy64(void *d, const void *s, uint64_t n) { return memcpy(d, s, (size_t)n); }
+
+DEBIG_API void init_PNG_decoder(void *(*malloc_funcptr)(size_t))
+{
+    (void)malloc_funcptr;
+    decode_png_init(legacy_malloc64, free, legacy_memset64, legacy_memcpy64, 120000000u, 0);
+}
+DEBIG_API void get_PNG_width_height(const uint8_t *in, const uint64_t in_size, uint32_t *w, uint32_t *h,
+                                    uint32_t *out_good)
+{
+    uint8_t g = 0;
+    decode_png_get_width_height(in, in_size, w, h, &g);
+    *out_good = g;
+}
+DEBIG_API void decode_PNG(const uint8_t *in, const uint64_t in_size, const uint8_t *out_rgba_values,
+                          const uint64_t rgba_values_size, uint32_t *out_good)
+{
+    uint8_t g = 0;
+    decode_png(in, in_size, out_rgba_values, rgba_values_size, 0, &g);
+    *out_good = g;
+}
