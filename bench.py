@@ -35,13 +35,6 @@ STREAMS_PER_KIND = 4096
 STREAM_BYTES = 65536
 
 
-def build_shard_map(world, per_kind):
-    """rank 0's table: global stream id -> (rank, kind, local index).  Round-robin."""
-    total = world * per_kind
-    ids = np.arange(total, dtype=np.int64)
-    return np.stack([ids, ids % world, ids // world], axis=1)  # [id, rank, local]
-
-
 def cpu_baseline(sample_fixed, sample_stored):
     """Reference (or oracle port) single-thread throughput on a bounded sample."""
     from oracle import binding
@@ -89,6 +82,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
@@ -102,12 +96,10 @@ def main():
 
     per = args.streams
     # ---- shard map: rank 0 builds it, RCCL broadcasts it (the only collective on the path)
-    smap = torch.zeros((world * per, 3), dtype=torch.int64, device=dev)
-    if rank == 0:
-        smap.copy_(torch.from_numpy(build_shard_map(world, per)))
-    if world > 1:
-        dist.broadcast(smap, src=0)
-    mine = smap[smap[:, 1] == rank][:, 0].cpu().numpy()  # global stream ids of this rank
+    from debigulator_amd import shard
+
+    smap = shard.broadcast_shard_map(world * per, dev, dist if world > 1 else None)
+    mine = shard.my_streams(smap, rank)  # global stream ids of this rank
     assert len(mine) == per
 
     # ---- synthesise this rank's shard (deterministic) and park it in HBM

@@ -1,0 +1,57 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/*.h declares
+(no compute call is made: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions(header_text):
+    text = re.sub(r"/\*.*?\*/", "", header_text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    names = set()
+    for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text):
+        name = m.group(1)
+        before = text[: m.start()].rstrip()
+        # a function declaration's name is preceded by a type token or '*', not by '(' or ','
+        if name in ("defined", "sizeof", "__attribute__", "visibility") or before.endswith(("(", ",", "#define")):
+            continue
+        if re.search(r"(\*|\b[A-Za-z_][A-Za-z0-9_]*)\s*$", before) and not before.endswith(("return", "typedef")):
+            names.add(name)
+    return names
+
+
+def test_library_exports_every_declared_symbol(native_lib):
+    declared = set()
+    for h in ("debig_hip.h", "inflate.h", "decode_png.h", "decode_gz.h"):
+        declared |= _declared_functions(open(os.path.join(ROOT, "include", h)).read())
+    # `inflate` is a macro alias for debig_inflate (zlib owns the plain symbol); function-pointer
+    # parameter names are not functions
+    declared -= {"inflate", "malloc_funcptr", "arg_memset_func", "arg_memcpy_func", "arg_free_funcptr",
+                 "arg_memset_funcptr", "free_funcptr"}
+    assert {"debig_hip_inflate_batch", "debig_hip_png_defilter_batch", "debig_inflate", "inflate_init",
+            "inflate_destroy", "decode_png", "decode_png_init", "decode_png_deinit",
+            "decode_png_get_width_height", "decode_gz", "init_decode_gz", "decode_PNG", "init_PNG_decoder",
+            "get_PNG_width_height", "debig_inflate_batch", "debig_decode_png_batch",
+            "debig_decode_gz_batch"} <= declared
+    missing = [n for n in sorted(declared) if not hasattr(native_lib, n)]
+    assert not missing, missing
+
+
+def test_plain_inflate_symbol_is_not_exported(native_lib):
+    """zlib exports `inflate`; libamdhip64/librccl/python load zlib.  Ours must not shadow it."""
+    from debigulator_amd import _native
+
+    out = os.popen(f"nm -D --defined-only {_native.LIB_PATH}").read()
+    syms = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    assert "inflate" not in syms and "debig_inflate" in syms
+
+
+def test_struct_layouts_match_header():
+    from debigulator_amd import _native as N
+    from debigulator_amd.batch import RESULT_DTYPE, STREAM_DTYPE
+
+    assert ctypes.sizeof(N.DebigStream) == 56 == STREAM_DTYPE.itemsize
+    assert ctypes.sizeof(N.DebigResult) == 64 == RESULT_DTYPE.itemsize
+    assert ctypes.sizeof(N.DebigPngImage) == 40

@@ -1,0 +1,142 @@
+"""CPU: the product's HIP kernels compiled for the lock-step SIMT emulator
+(tools/simt_emu) against the oracle / golden fixtures.  This exercises the very kernel
+source that hipcc builds for gfx950 -- indexing, tiling, speculation, LZ77 resolve,
+de-filter -- on machines without a GPU.  (The emulator says nothing about speed.)"""
+import ctypes as C
+import hashlib
+import json
+import os
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+import emu_binding as eb
+from debigulator_amd import workload
+from debigulator_amd._native import DebigPngImage, DebigPngResult
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return eb.load_emu()
+
+
+def test_known_answers_and_corpus(emu):
+    items = json.load(open(os.path.join(GOLD, "kat.json")))
+    items += json.load(open(os.path.join(GOLD, "corpus_zlib.json")))[:80]
+    raws = [bytes.fromhex(k["raw_hex"]) for k in items]
+    caps = [k["recipient_size"] for k in items]
+    outs, arena, offs = eb.emu_inflate(emu, raws, caps, in_misalign=3, out_misalign=5)
+    for k, (good, final, out, r) in zip(items, outs):
+        assert good == k["good"] and final == k["final"], k.get("name")
+        want = k.get("out_hex")
+        if want is not None:
+            assert out.hex() == want
+        else:
+            assert hashlib.sha256(out).hexdigest() == k["out_sha256"]
+    for (io, oo), cap in zip(offs, caps):  # guard bytes behind every recipient are intact
+        assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
+
+
+@pytest.mark.parametrize("kind", ["stored", "fixed", "dynamic"])
+def test_cfg2_streams(emu, oracle, kind):
+    pairs = workload.make_streams(kind, 3, 65536)
+    raws = [p[0] for p in pairs]
+    caps = [max(65537, len(r)) for r in raws]
+    outs, _, _ = eb.emu_inflate(emu, raws, caps)
+    for (good, final, out, r), (raw, plain) in zip(outs, pairs):
+        assert (good, final) == (1, 65536) and out == plain.tobytes()
+        if kind != "stored":
+            assert r.n_windows > 0 and r.n_rounds / r.n_windows < 6  # speculation converges fast
+
+
+def test_corrupt_streams_agree_with_oracle(emu, oracle):
+    rng = random.Random(4)
+    raws, caps = [], []
+    for it in range(60):
+        data = bytes(rng.choice(b"abcdefgh ") for _ in range(rng.randint(50, 3000)))
+        raw = bytearray(zlib.compress(data, rng.choice([1, 6, 9]))[2:-4])
+        if rng.random() < 0.5:
+            raw = raw[: rng.randint(5, len(raw))]
+        else:
+            raw[rng.randrange(len(raw))] ^= 1 << rng.randrange(8)
+        raws.append(bytes(raw))
+        caps.append(len(data) * 4 + 64)
+    outs, arena, offs = eb.emu_inflate(emu, raws, caps)
+    for raw, cap, (good, final, out, r) in zip(raws, caps, outs):
+        eg, ef, eo, st = oracle.inflate(raw, cap, want_stats=True)
+        if st.ub_flags & (0x10 | 0x02):
+            continue
+        assert (good, final, out) == (eg, ef, eo)
+
+
+def test_p2_aliasing_replay_matches_reference_digest(emu):
+    """phoebus.png: the inflate kernel with the decode_png aliasing parameters + the
+    de-filter kernel reproduce the reference's (corrupted-tail) output."""
+    gold = json.load(open(os.path.join(GOLD, "resources.json")))["png"]["phoebus.png"]
+    data = open(os.path.join(GOLD, "resources", "phoebus.png"), "rb").read()
+    w, h = gold["width"], gold["height"]
+    # host-side container walk (same rules as csrc/host/debig_png.c), in python for the test
+    at, z = 8, b""
+    while at + 8 <= len(data):
+        ln = int.from_bytes(data[at:at + 4], "big")
+        if data[at + 4:at + 8] == b"IDAT":
+            z += data[at + 8:at + 8 + ln]
+        at += 12 + ln
+    raw = z[2:-4]
+    est = 4 * w * h + h + 1
+    s0 = est - 772 + ((16 - (est & 15)) & 15)
+    outs, arena, offs = eb.emu_inflate(emu, [raw], [est], p2=[(s0, est)])
+    good, final, stream, r = outs[0]
+    assert good == 1 and final == est - 1
+    rgba = _emu_defilter(emu, stream, w, h, 6)
+    assert hashlib.sha256(rgba.tobytes()).hexdigest() == gold["rgba_sha256"]
+
+
+def _emu_defilter(emu, stream, w, h, ct, palette=None):
+    emu.emu_png_defilter_batch.restype = C.c_int
+    emu.emu_png_defilter_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    sa = np.zeros(len(stream) + 1024 + 768, dtype=np.uint8)
+    sa[1:1 + len(stream)] = np.frombuffer(stream, dtype=np.uint8)  # odd offset: rows are never aligned
+    pal_off = (1 + len(stream) + 15) // 16 * 16
+    if palette is not None:
+        sa[pal_off:pal_off + 768] = palette
+    rgba = np.zeros(4 * w * h + 64, dtype=np.uint8)
+    img = (DebigPngImage * 1)()
+    img[0].stream_off, img[0].rgba_off, img[0].pal_off = 1, 0, pal_off
+    img[0].width, img[0].height, img[0].color_type, img[0].asserts_off = w, h, ct, 0
+    res = (DebigPngResult * 1)()
+    assert emu.emu_png_defilter_batch(sa.ctypes.data, rgba.ctypes.data, img, res, 1) == 0
+    assert res[0].good == 1
+    return rgba[: 4 * w * h]
+
+
+def test_defilter_kernel_all_filter_types(emu, oracle):
+    for p in json.load(open(os.path.join(GOLD, "png_synth.json"))):
+        if not p["good"]:
+            # the stored-block 33x7 image: its DEFLATE stream is LONGER than the recipient the
+            # reference hands to inflate (est = 4wh+h+1), so the reference's own gate
+            # recipient_size < compressed_input_size rejects a valid PNG (Q1)
+            continue
+        png = bytes.fromhex(p["png_hex"])
+        at, z, plte = 8, b"", None
+        while at + 8 <= len(png):
+            ln = int.from_bytes(png[at:at + 4], "big")
+            typ = png[at + 4:at + 8]
+            if typ == b"IDAT":
+                z += png[at + 8:at + 8 + ln]
+            if typ == b"PLTE":
+                plte = np.frombuffer(png[at + 8:at + 8 + ln], dtype=np.uint8).reshape(-1, 3)
+            at += 12 + ln
+        stream = zlib.decompress(z)
+        pal = None
+        if plte is not None:
+            pal = np.zeros(768, dtype=np.uint8)
+            pal[0:len(plte)] = plte[:, 0]
+            pal[256:256 + len(plte)] = plte[:, 1]
+            pal[512:512 + len(plte)] = plte[:, 2]
+        rgba = _emu_defilter(emu, stream, p["w"], p["h"], p["ct"], pal)
+        assert hashlib.sha256(rgba.tobytes()).hexdigest() == p["rgba_sha256"], (p["w"], p["h"], p["ct"], p["ftype"])

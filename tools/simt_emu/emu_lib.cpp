@@ -4,6 +4,7 @@
 #include "hip_emu.h"
 #include "../../include/debig_hip.h"
 #include "../../debigulator_amd/csrc/inflate_kernel.inc"
+#include "../../debigulator_amd/csrc/png_kernel.inc"
 
 extern "C" int emu_inflate_batch(const void *in, void *out, const debig_stream *streams,
                                  debig_result *results, uint32_t n, uint32_t grid)
@@ -15,5 +16,13 @@ extern "C" int emu_inflate_batch(const void *in, void *out, const debig_stream *
         EMU_LAUNCH(debig_fixed_tables_kernel, 1, 64, ft);
     }
     EMU_LAUNCH(debig_inflate_kernel, grid, 64, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft);
+    return 0;
+}
+
+extern "C" int emu_png_defilter_batch(const void *streams_arena, void *rgba_arena, const debig_png_image *images,
+                                      debig_png_result *results, uint32_t n)
+{
+    EMU_LAUNCH(debig_png_defilter_kernel, n, 64, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images,
+               results, n);
     return 0;
 }
