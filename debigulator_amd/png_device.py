@@ -1,0 +1,93 @@
+"""PNG decode with everything resident in HBM (BASELINE configs 3 and 4).
+
+Host side only splits the container (pure python here; the C drop-in layer does the same in
+csrc/host/debig_png.c): IDAT payloads -> input arena; then ONE inflate launch
+(debig_hip_inflate_batch, with the decode_png aliasing-replay parameters) and ONE de-filter
+launch (debig_hip_png_defilter_batch).  Used by the GPU tests and tools/bench_png.py.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .batch import DeviceBatch, pack_streams
+
+
+def split_png(data):
+    """-> dict(w, h, ct, raw (DEFLATE payload handed to inflate), palette[768] or None)"""
+    d = bytes(data)
+    assert d[1:4] == b"PNG"
+    at, z, pal, w, h, ct = 8, [], None, 0, 0, 0
+    while at + 8 <= len(d):
+        ln = int.from_bytes(d[at:at + 4], "big")
+        typ = d[at + 4:at + 8]
+        body = d[at + 8:at + 8 + ln]
+        if typ == b"IHDR":
+            w, h, ct = int.from_bytes(body[0:4], "big"), int.from_bytes(body[4:8], "big"), body[9]
+        elif typ == b"PLTE":
+            p = np.frombuffer(body, dtype=np.uint8).reshape(-1, 3)
+            pal = np.zeros(768, dtype=np.uint8)
+            pal[0:len(p)], pal[256:256 + len(p)], pal[512:512 + len(p)] = p[:, 0], p[:, 1], p[:, 2]
+        elif typ == b"IDAT":
+            z.append(body)
+        at += 12 + ln
+    zz = b"".join(z)
+    return {"w": w, "h": h, "ct": ct, "raw": zz[2:-4], "palette": pal}
+
+
+class DevicePngBatch:
+    def __init__(self, pngs, device="cuda:0", strict=False):
+        import torch
+
+        self.torch = torch
+        self.items = [split_png(p) for p in pngs]
+        n = self.n = len(self.items)
+        raws = [it["raw"] for it in self.items]
+        ests = [4 * it["w"] * it["h"] + it["h"] + 1 for it in self.items]
+        p2 = None if strict else [(e - 772 + ((16 - (e & 15)) & 15), e) for e in ests]
+        in_arena, streams, out_bytes = pack_streams(raws, ests, p2=p2)
+        # palettes live behind the stream arena
+        pal_base = out_bytes
+        self.inflate = DeviceBatch(in_arena, streams, out_bytes + 768 * n + 64, device)
+        img = (N.DebigPngImage * n)()
+        off = 0
+        self.rgba_off = []
+        for i, it in enumerate(self.items):
+            img[i].stream_off = int(streams[i]["out_off"])
+            img[i].rgba_off = off
+            img[i].pal_off = pal_base + 768 * i
+            img[i].width, img[i].height, img[i].color_type, img[i].asserts_off = it["w"], it["h"], it["ct"], 0
+            self.rgba_off.append(off)
+            off += (4 * it["w"] * it["h"] + 31) // 16 * 16
+            if it["palette"] is not None:
+                self.inflate.d_out[pal_base + 768 * i: pal_base + 768 * (i + 1)] = torch.from_numpy(it["palette"]).to(device)
+        self.rgba_bytes = sum(4 * it["w"] * it["h"] for it in self.items)
+        self.c_bytes = sum(len(r) for r in raws)
+        self.s_bytes = sum(e - 1 for e in ests)
+        self.d_rgba = torch.zeros(off + 64, dtype=torch.uint8, device=device)
+        self.d_img = torch.frombuffer(bytearray(bytes(img)), dtype=torch.uint8).to(device)
+        self.d_ires = torch.zeros(n * C.sizeof(N.DebigPngResult), dtype=torch.uint8, device=device)
+        self.lib = N.lib()
+
+    def launch(self, stream=None):
+        torch = self.torch
+        if stream is None:
+            stream = torch.cuda.current_stream(self.inflate.device)
+        self.inflate.launch(stream)
+        rc = self.lib.debig_hip_png_defilter_batch(self.inflate.d_out.data_ptr(), self.d_rgba.data_ptr(),
+                                                   self.d_img.data_ptr(), self.d_ires.data_ptr(), self.n,
+                                                   C.c_void_p(stream.cuda_stream))
+        N.check(rc, "debig_hip_png_defilter_batch")
+
+    def launch_inflate_only(self, stream=None):
+        self.inflate.launch(stream)
+
+    def results(self):
+        self.torch.cuda.synchronize()
+        ires = self.d_ires.cpu().numpy().view(np.dtype([("good", "<u4"), ("bad_row", "<u4")]))
+        return self.inflate.results(), ires
+
+    def rgba(self, i):
+        it = self.items[i]
+        o = self.rgba_off[i]
+        return self.d_rgba[o:o + 4 * it["w"] * it["h"]].cpu().numpy()

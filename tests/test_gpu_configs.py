@@ -1,0 +1,118 @@
+"""GPU: the other BASELINE.json configs as parity cases (config 2 is tests/test_gpu_inflate.py
+and bench.py): config 3 = 1024 PNGs cycled from the reference's 15 sample files, config 4
+shape = large all-Paeth RGBA PNGs (scaled down so the oracle finishes in seconds, plus a
+size-independent property at a larger size), config 5 shape = gzip members of 1 MiB."""
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from debigulator_amd import workload
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def test_cfg3_1024_pngs_resident(gpu_device):
+    from debigulator_amd.png_device import DevicePngBatch
+
+    gold = json.load(open(os.path.join(GOLD, "resources.json")))["png"]
+    files = [f for f in sorted(glob.glob(os.path.join(GOLD, "resources", "*.png")))
+             if not f.endswith("backgrounddetailed1.png")]  # ct 2: reference output is the P3 artefact
+    datas = [open(f, "rb").read() for f in files]
+    pngs = [datas[i % len(datas)] for i in range(1024)]
+    b = DevicePngBatch(pngs, device=gpu_device)
+    b.launch()
+    res, ires = b.results()
+    assert (res["good"] == 1).all() and (ires["good"] == 1).all()
+    for i in list(range(0, 28)) + list(range(1000, 1024)):
+        name = os.path.basename(files[i % len(files)])
+        assert sha(b.rgba(i).tobytes()) == gold[name]["rgba_sha256"], (i, name)
+
+
+def test_cfg4_shape_paeth_rgba(gpu_device, oracle):
+    """all rows Paeth, RGBA, dynamic Huffman, 64 KiB IDAT chunks; 512x512 vs the oracle byte for byte"""
+    from debigulator_amd.png_device import DevicePngBatch
+
+    pngs, pix = [], []
+    for s in range(4):
+        p, x = workload.make_png(7000 + s, 512, 512, ct=6, ftype=4, noise=24, enc="dynamic", idat_chunk=65536)
+        pngs.append(p)
+        pix.append(x)
+    b = DevicePngBatch(pngs, device=gpu_device)
+    b.launch()
+    res, ires = b.results()
+    assert (res["good"] == 1).all() and (ires["good"] == 1).all()
+    for i in range(4):
+        good, want = oracle.decode_png(pngs[i])
+        assert good == 1
+        got = b.rgba(i)
+        assert np.array_equal(got, want)
+        # the generator's own pixels (round trip: filter -> deflate -> inflate -> de-filter)
+        assert np.array_equal(got.reshape(512, 2048), pix[i])
+
+
+def test_cfg4_roundtrip_property_large(gpu_device):
+    """size-independent property at 2048x2048 (16 MiB of RGBA per image): de-filter(inflate(
+    deflate(filter(pixels)))) == pixels"""
+    from debigulator_amd.png_device import DevicePngBatch
+
+    p, x = workload.make_png(7100, 2048, 2048, ct=6, ftype=4, noise=24, enc="dynamic", idat_chunk=65536)
+    b = DevicePngBatch([p, p], device=gpu_device)
+    b.launch()
+    res, ires = b.results()
+    assert (res["good"] == 1).all() and (ires["good"] == 1).all()
+    assert int(res[0]["final_size"]) == 2048 * (2048 * 4 + 1)
+    assert np.array_equal(b.rgba(1).reshape(2048, 8192), x)
+
+
+def test_cfg5_shape_gzip_members(gpu_device, oracle):
+    """gzip members of 1 MiB (text-like, dynamic Huffman, EOB >= 8 bits so the tail rule never
+    truncates): header located on the host, payloads inflated in one launch."""
+    from debigulator_amd.batch import DeviceBatch
+
+    members, plains, raws, caps = [], [], [], []
+    for i in range(48):
+        plain = workload.payload("text", workload.SEED0 + 100000 + i, 1 << 20)
+        raw = workload.encode("dynamic", plain)
+        gz = workload.gzip_member(raw, plain)
+        ok, off, ln = oracle.gz_locate(gz)
+        assert ok and gz[off:off + ln] == raw
+        members.append(gz)
+        plains.append(plain)
+        raws.append(gz[off:off + ln])
+        caps.append((1 << 20) + 1)
+    b = DeviceBatch.from_streams(raws, caps, device=gpu_device)
+    b.launch()
+    res = b.results()
+    assert (res["good"] == 1).all() and (res["final_size"] == (1 << 20)).all()
+    host = b.outputs_host()
+    import zlib
+
+    for i in range(48):
+        off = int(b.streams_host[i]["out_off"])
+        got = host[off:off + (1 << 20)]
+        assert np.array_equal(got, plains[i])
+        # trailer: CRC32 + ISIZE of the member (the reference never checks them; we can)
+        crc, isz = np.frombuffer(members[i][-8:], dtype="<u4")
+        assert zlib.crc32(got.tobytes()) == crc and isz == (1 << 20)
+    # and three of them through the oracle, byte for byte
+    for i in (0, 17, 47):
+        good, out, n = oracle.decode_gz(members[i], (1 << 20) + 16)
+        assert good == 1 and out == plains[i].tobytes()
+
+
+def test_drop_in_decode_gz_batch(gpu_device):
+    from debigulator_amd import api
+
+    plain = workload.payload("text", 99, 300000)
+    gz = workload.gzip_member(workload.encode("dynamic", plain), plain)
+    good, out = api.decode_gz(gz)
+    assert good == 1 and out == plain.tobytes()
