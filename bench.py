@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--streams", type=int, default=STREAMS_PER_KIND, help="streams per kind per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=64, help="streams per kind checked against the generator")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "the N>1 code path on one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -92,9 +95,15 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.one_device:
+            local_rank = 0
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(args.backend)
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
+    coll_dev = dev if args.backend == "nccl" else "cpu"  # where collective tensors live
 
     from debigulator_amd import workload
     from debigulator_amd.batch import DeviceBatch
@@ -103,7 +112,7 @@ def main():
     # ---- shard map: rank 0 builds it, RCCL broadcasts it (the only collective on the path)
     from debigulator_amd import shard
 
-    smap = shard.broadcast_shard_map(world * per, dev, dist if world > 1 else None)
+    smap = shard.broadcast_shard_map(world * per, coll_dev, dist if world > 1 else None)
     mine = shard.my_streams(smap, rank)  # global stream ids of this rank
     assert len(mine) == per
 
@@ -155,7 +164,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
@@ -223,7 +232,7 @@ def main():
                 "avg_launch_ms": stored_ms,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             try:
                 line["cpu_baseline"] = cpu_baseline(pairs_keep["fixed"], pairs_keep["stored"])
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not bench.py's headline): PNG decode with everything resident in
+HBM -- BASELINE config 3 (1024 PNGs cycled from the reference's sample files) and the config 4
+shape (all-Paeth RGBA 8192x8192, a few images instead of 256)."""
+import glob, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from debigulator_amd import workload
+from debigulator_amd.png_device import DevicePngBatch
+
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+if which == "cfg3":
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "resources", "*.png")))
+             if not f.endswith("backgrounddetailed1.png")]
+    datas = [open(f, "rb").read() for f in files]
+    pngs = [datas[i % len(datas)] for i in range(1024)]
+    label = "cfg3: 1024 PNGs cycled from 14 reference sample files"
+else:
+    side = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+    count = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    t0 = time.time()
+    distinct = [workload.make_png(9000 + s, side, side, ct=6, ftype=4, noise=24, enc="dynamic", idat_chunk=65536)[0]
+                for s in range(min(count, 2))]
+    pngs = [distinct[i % len(distinct)] for i in range(count)]
+    label = f"cfg4 shape: {count} x {side}x{side} RGBA all-Paeth PNGs (generated in {time.time()-t0:.0f} s)"
+b = DevicePngBatch(pngs)
+t_all = timeit(b.launch)
+t_inf = timeit(b.launch_inflate_only)
+res, ires = b.results()
+assert (res["good"] == 1).all() and (ires["good"] == 1).all()
+P, Cb, Sb = b.rgba_bytes, b.c_bytes, b.s_bytes
+print(label)
+print(f"  inflate+defilter {t_all:9.3f} ms  {P/t_all/1e6:8.1f} GB/s of RGBA   (C={Cb/1e6:.1f} MB, S={Sb/1e6:.1f} MB, P={P/1e6:.1f} MB)")
+print(f"  inflate only     {t_inf:9.3f} ms  {Sb/t_inf/1e6:8.1f} GB/s of scanline stream;  de-filter ~{t_all-t_inf:9.3f} ms "
+      f"{(Sb+P)/(max(t_all-t_inf,1e-6))/1e6:8.1f} GB/s (S+P)")
