@@ -181,6 +181,14 @@ def main():
         ach_fixed = alg_fixed / (fixed_ms * 1e-3) / 1e9
         ach_stored = alg_stored / (stored_ms * 1e-3) / 1e9
         res_f = fx.results()
+        # HBM traffic per launch from the PMC passes of this same command (profiles/pmc_traffic.json,
+        # made by tools/pmc_traffic.sh + tools/pmc_summary.py); null if that file is absent
+        traffic = {}
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        except (OSError, ValueError):
+            pass
+        scale = per / STREAMS_PER_KIND
         line = {
             "metric": "decompressed GB/s (whole node) + % HBM roofline, bit-exact vs reference",
             "value": value,
@@ -216,7 +224,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": ach_fixed / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": (traffic.get("fixed_bytes_per_launch") or 0) * scale or None,
                 "algorithmic_bytes_per_launch": alg_fixed,
                 "avg_launch_ms": fixed_ms,
             },
@@ -227,7 +235,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": ach_stored / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": (traffic.get("stored_bytes_per_launch") or 0) * scale or None,
                 "algorithmic_bytes_per_launch": alg_stored,
                 "avg_launch_ms": stored_ms,
             },
