@@ -3,15 +3,15 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-Workload (per rank; SURVEY.md 8d "cfg2"): 4096 stored-block streams + 4096
-fixed-Huffman streams, every stream inflating to one 64 KiB block; streams are
+Workload (per rank; SURVEY.md 8d "cfg2"): 4096 fixed-Huffman streams + 4096
+stored-block streams, every stream inflating to one 64 KiB block; streams are
 generated deterministically (tools/streamgen.c, seed 0xDEB16 + global stream index).
-One "step" = one pass of the hot path (the batched inflate kernel through the C-ABI,
-include/debig_hip.h) over the whole batch, inputs already resident in HBM.
+One "step" = one pass of the hot path (ONE launch of the batched inflate kernel through
+the C-ABI, include/debig_hip.h) over the whole batch, inputs already resident in HBM.
 
   value      decompressed GB/s, whole job  = sum over ranks of D bytes / max-over-ranks time
-  roofline   the dominant kernel launch (fixed-Huffman batch): algorithmic bytes C + D per
-             launch / average launch duration (HIP events on the launch stream)
+  roofline   that launch: algorithmic bytes C + D of the batch / average launch duration
+             (events on the launch stream); --variants adds each stream kind timed alone
   cpu_baseline  the compiled reference (oracle/_ref, single thread) or, if that prebuilt
              library is absent, the oracle port -- timed on a bounded sample of the same streams
 
@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--streams", type=int, default=STREAMS_PER_KIND, help="streams per kind per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=64, help="streams per kind checked against the generator")
+    ap.add_argument("--variants", action="store_true", help="also time each stream kind alone (untimed extra)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N>1 code path on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -118,48 +119,45 @@ def main():
 
     # ---- synthesise this rank's shard (deterministic) and park it in HBM
     ncpu = max(1, min(16, (os.cpu_count() or 8) // max(1, min(world, 8))))
-    batches = {}
+    from concurrent.futures import ThreadPoolExecutor
+
     pairs_keep = {}
-    for kind in ("stored", "fixed"):
-        from concurrent.futures import ThreadPoolExecutor
-
+    for kind in ("fixed", "stored"):
         with ThreadPoolExecutor(ncpu) as ex:
-            pairs = list(ex.map(lambda g: workload.make_stream(kind, int(g), STREAM_BYTES), mine))
-        raws = [p[0] for p in pairs]
-        caps = [max(STREAM_BYTES + 1, len(r)) for r in raws]
-        batches[kind] = DeviceBatch.from_streams(raws, caps, device=dev)
-        batches[kind].c_bytes = sum(len(r) for r in raws)
-        batches[kind].d_bytes = STREAM_BYTES * len(raws)
-        pairs_keep[kind] = pairs
-
-    def step():
-        batches["stored"].launch()
-        batches["fixed"].launch()
+            pairs_keep[kind] = list(ex.map(lambda g: workload.make_stream(kind, int(g), STREAM_BYTES), mine))
+    # ONE batch = this rank's whole shard: the long-running Huffman streams first, the stored
+    # ones behind them (workgroups are dispatched in stream order)
+    all_pairs = pairs_keep["fixed"] + pairs_keep["stored"]
+    raws = [p[0] for p in all_pairs]
+    caps = [max(STREAM_BYTES + 1, len(r)) for r in raws]
+    batch = DeviceBatch.from_streams(raws, caps, device=dev)
+    c_fixed = sum(len(p[0]) for p in pairs_keep["fixed"])
+    c_stored = sum(len(p[0]) for p in pairs_keep["stored"])
+    c_bytes = c_fixed + c_stored
+    d_bytes = STREAM_BYTES * len(raws)
 
     for _ in range(args.warmup):
-        step()
+        batch.launch()
     torch.cuda.synchronize()
 
-    # ---- bit-exactness gate (untimed): sample of outputs vs the generator's plain bytes
-    for kind, b in batches.items():
-        res = b.results()
-        assert (res["good"] == 1).all(), f"{kind}: a stream failed"
-        assert (res["final_size"] == STREAM_BYTES).all(), f"{kind}: wrong size"
-        for i, (_, plain) in enumerate(pairs_keep[kind][: args.verify]):
-            assert b.output(i, res) == plain.tobytes(), f"{kind} stream {i} differs"
+    # ---- bit-exactness gate (untimed): sizes/flags of every stream, bytes of a sample
+    res = batch.results()
+    assert (res["good"] == 1).all(), "a stream failed"
+    assert (res["final_size"] == STREAM_BYTES).all(), "wrong size"
+    for base in (0, per):
+        for i in range(base, base + args.verify):
+            assert batch.output(i, res) == all_pairs[i][1].tobytes(), f"stream {i} differs"
 
     # ---- timed region: exactly K steps between barrier+sync on both sides
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        batches["stored"].launch()
+        batch.launch()
         ev[k][1].record()
-        batches["fixed"].launch()
-        ev[k][2].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -168,27 +166,38 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    launch_ms = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)]))
 
-    stored_ms = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)]))
-    fixed_ms = float(np.mean([ev[k][1].elapsed_time(ev[k][2]) for k in range(args.steps)]))
+    variants = None
+    if args.variants and rank == 0:  # untimed extra: each kind launched alone
+        variants = {}
+        for kind, lo, cb in (("fixed_huffman", 0, c_fixed), ("stored", per, c_stored)):
+            sub = DeviceBatch.from_streams(raws[lo:lo + per], caps[lo:lo + per], device=dev)
+            for _ in range(2):
+                sub.launch()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                sub.launch()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            variants[kind] = {"kernel_ms": ms, "decompressed_GBps": per * STREAM_BYTES / ms / 1e6,
+                              "roofline_frac": (cb + per * STREAM_BYTES) / ms / 1e6 / HBM_PEAK_GBS}
 
     if rank == 0:
-        d_per_rank = sum(b.d_bytes for b in batches.values())
-        value = world * d_per_rank * args.steps / dt_max / 1e9
-        fx, sb = batches["fixed"], batches["stored"]
-        alg_fixed = fx.c_bytes + fx.d_bytes
-        alg_stored = sb.c_bytes + sb.d_bytes
-        ach_fixed = alg_fixed / (fixed_ms * 1e-3) / 1e9
-        ach_stored = alg_stored / (stored_ms * 1e-3) / 1e9
-        res_f = fx.results()
+        value = world * d_bytes * args.steps / dt_max / 1e9
+        alg = c_bytes + d_bytes
+        ach = alg / (launch_ms * 1e-3) / 1e9
+        rf = res[:per]
         # HBM traffic per launch from the PMC passes of this same command (profiles/pmc_traffic.json,
         # made by tools/pmc_traffic.sh + tools/pmc_summary.py); null if that file is absent
-        traffic = {}
+        traffic = None
         try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        except (OSError, ValueError):
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            traffic = tj["bytes_per_launch"] * (per / STREAMS_PER_KIND)
+        except (OSError, ValueError, KeyError):
             pass
-        scale = per / STREAMS_PER_KIND
         line = {
             "metric": "decompressed GB/s (whole node) + % HBM roofline, bit-exact vs reference",
             "value": value,
@@ -203,43 +212,31 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"cfg2: per GPU {per} stored + {per} fixed-Huffman DEFLATE streams, 64 KiB each "
-                            f"(one 64 KiB block per stream; stored = 65535+1 byte blocks), seed 0xDEB16+i",
+                "workload": f"cfg2: per GPU {per} fixed-Huffman + {per} stored DEFLATE streams, 64 KiB each, one "
+                            f"batch = one kernel launch (one 64 KiB block per stream; stored = 65535+1 byte "
+                            f"blocks), seed 0xDEB16+i",
                 "streams_per_gpu": 2 * per,
-                "decompressed_bytes_per_gpu": d_per_rank,
-                "compressed_bytes_per_gpu": fx.c_bytes + sb.c_bytes,
+                "decompressed_bytes_per_gpu": d_bytes,
+                "compressed_bytes_per_gpu": c_bytes,
+                "fixed_huffman_ratio": per * STREAM_BYTES / c_fixed,
                 "sharding": "round-robin by stream id, shard map broadcast over RCCL, no payload collective",
                 "bit_exact_checked": f"{args.verify} streams per kind byte-for-byte + all sizes/good flags",
-            },
-            "variants": {
-                "fixed_huffman": {"decompressed_GBps": fx.d_bytes / (fixed_ms * 1e-3) / 1e9, "kernel_ms": fixed_ms,
-                                  "ratio": fx.d_bytes / fx.c_bytes,
-                                  "avg_spec_rounds_per_window": float(res_f["n_rounds"].sum()) / max(1, float(res_f["n_windows"].sum()))},
-                "stored": {"decompressed_GBps": sb.d_bytes / (stored_ms * 1e-3) / 1e9, "kernel_ms": stored_ms},
+                "avg_spec_rounds_per_window": float(rf["n_rounds"].sum()) / max(1, float(rf["n_windows"].sum())),
             },
             "roofline": {
-                "kernel": "debig_inflate_kernel (fixed-Huffman launch: the dominant launch of a step)",
+                "kernel": "debig_inflate_kernel (the step's only launch)",
                 "bound": "hbm",
-                "achieved": ach_fixed,
+                "achieved": ach,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": ach_fixed / HBM_PEAK_GBS,
-                "traffic": (traffic.get("fixed_bytes_per_launch") or 0) * scale or None,
-                "algorithmic_bytes_per_launch": alg_fixed,
-                "avg_launch_ms": fixed_ms,
-            },
-            "roofline_stored": {
-                "kernel": "debig_inflate_kernel (stored-block launch)",
-                "bound": "hbm",
-                "achieved": ach_stored,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": ach_stored / HBM_PEAK_GBS,
-                "traffic": (traffic.get("stored_bytes_per_launch") or 0) * scale or None,
-                "algorithmic_bytes_per_launch": alg_stored,
-                "avg_launch_ms": stored_ms,
+                "frac": ach / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg,
+                "avg_launch_ms": launch_ms,
             },
         }
+        if variants:
+            line["variants"] = variants
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             try:
                 line["cpu_baseline"] = cpu_baseline(pairs_keep["fixed"], pairs_keep["stored"])
