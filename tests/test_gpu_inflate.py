@@ -163,3 +163,33 @@ def test_roundtrip_full_size_property(gpu_device):
     for i, (_, plain) in enumerate(pairs):
         off = int(b.streams_host[i]["out_off"])
         assert np.array_equal(host[off:off + 65536], plain), i
+
+
+def test_mass_corruption_stays_in_bounds_and_agrees(oracle, gpu_device):
+    """20 000 damaged streams in one launch: every one must agree with the oracle (good flag,
+    final size, bytes) and nothing may be written past recipient_size -- the kernel's loops
+    are data dependent, so this is also the no-hang / no-fault test."""
+    rng = random.Random(2026)
+    bases = []
+    for k in range(40):
+        data = _payload(rng, rng.randint(200, 6000), rng.randint(0, 4))
+        strat = rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE])
+        bases.append((_zlib_raw(data, rng.choice([1, 6, 9]), strat, 9, rng.randint(0, 2), rng), len(data)))
+    raws, caps = [], []
+    for it in range(20000):
+        raw, n = bases[it % len(bases)]
+        raw = bytearray(raw)
+        mode = rng.randrange(4)
+        if mode == 0:
+            raw = raw[: rng.randint(5, len(raw))]
+        elif mode == 1:
+            for _ in range(rng.randint(1, 4)):
+                raw[rng.randrange(len(raw))] ^= 1 << rng.randrange(8)
+        elif mode == 2:
+            i = rng.randrange(len(raw))
+            raw[i:i + rng.randint(1, 8)] = bytes(rng.getrandbits(8) for _ in range(rng.randint(1, 8)))
+        else:
+            raw = raw + bytes(rng.getrandbits(8) for _ in range(rng.randint(1, 64)))
+        raws.append(bytes(raw))
+        caps.append(max(n * 3 + 64, len(raw)))
+    _check(oracle, gpu_device, raws, caps)
