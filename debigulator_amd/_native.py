@@ -25,7 +25,8 @@ class DebigResult(C.Structure):
 class DebigPngImage(C.Structure):
     _fields_ = [("stream_off", C.c_uint64), ("rgba_off", C.c_uint64), ("pal_off", C.c_uint64),
                 ("width", C.c_uint32), ("height", C.c_uint32), ("color_type", C.c_uint32),
-                ("asserts_off", C.c_uint32)]
+                ("asserts_off", C.c_uint32), ("tmp_off", C.c_uint64), ("replay_p3", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 class DebigPngResult(C.Structure):

@@ -58,6 +58,10 @@ int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena
     hipLaunchKernelGGL(debig_png_defilter_kernel, dim3(n), dim3(64), 0, (hipStream_t)hip_stream,
                        (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images,
                        d_results, n);
+    // colour type 2 images that ask for the reference's exact (P3) output; a no-op otherwise
+    hipLaunchKernelGGL(debig_png_p3_kernel, dim3(n), dim3(64), 0, (hipStream_t)hip_stream,
+                       (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images,
+                       d_results, n);
     return (int)hipGetLastError();
 }
 

@@ -232,6 +232,7 @@ DEBIG_API int debig_decode_png_batch(const uint8_t *const *inputs, const uint64_
             in_total += debig_align16(P[i].zsize) + 16;
             out_total += debig_align16(P[i].est) + 16 + 768; /* + room for the palette */
             rgba_total += debig_align16(out_sizes[i]) + 16;
+            if (P[i].ct == 2 && !strict) rgba_total += debig_align16(out_sizes[i]) + 16; /* P3 replay: second buffer */
         }
     }
     if ((rc = debig_devbuf_reserve(&c->in, in_total + 64)) || (rc = debig_devbuf_reserve(&c->out, out_total + 64)) ||
@@ -268,8 +269,18 @@ DEBIG_API int debig_decode_png_batch(const uint8_t *const *inputs, const uint64_
         im->height = P[i].h;
         im->color_type = P[i].ct;
         im->asserts_off = 0;
+        im->tmp_off = 0;
+        im->replay_p3 = 0;
         if (P[i].ct == 3) rc = debig_hip_memcpy_h2d((uint8_t *)c->out.ptr + im->pal_off, pals + 768u * i, 768, NULL);
         rgba_off += debig_align16(out_sizes[i]) + 16;
+        if (P[i].ct == 2 && !strict) {
+            /* the reference's RGB output depends on the caller's prior buffer contents (P3):
+             * upload them, and give the kernel its second buffer */
+            im->replay_p3 = 1;
+            im->tmp_off = rgba_off;
+            rgba_off += debig_align16(out_sizes[i]) + 16;
+            if (!rc) rc = debig_hip_memcpy_h2d((uint8_t *)c->rgba.ptr + im->rgba_off, outs[i], out_sizes[i], NULL);
+        }
         map[nimg++] = i;
     }
     if (!rc && nimg) {

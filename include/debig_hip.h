@@ -79,8 +79,15 @@ typedef struct debig_png_image {
     uint64_t rgba_off;   /* output, relative to d_rgba_arena; 4*w*h bytes              */
     uint64_t pal_off;    /* colour type 3: 768 bytes R[256] G[256] B[256], rel. to d_streams_arena */
     uint32_t width, height;
-    uint32_t color_type; /* 6 (RGBA), 3 (palette), 2 (RGB, spec-conforming expansion)   */
+    uint32_t color_type; /* 6 (RGBA), 3 (palette), 2 (RGB)                                */
     uint32_t asserts_off;/* 0: a filter byte > 4 fails the image (reference default build) */
+    /* colour type 2 only: replay_p3 = 1 reproduces the reference's output for RGB images bit
+     * for bit (its RGB->RGBA expansion runs inside the row loop): rgba_off
+     * must then hold the caller's PRIOR buffer contents and tmp_off a second 4*w*h byte
+     * buffer (relative to d_rgba_arena).  replay_p3 = 0: spec-conforming RGB -> RGBA. */
+    uint64_t tmp_off;
+    uint32_t replay_p3;
+    uint32_t reserved;
 } debig_png_image;
 
 typedef struct debig_png_result {

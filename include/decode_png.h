@@ -10,8 +10,9 @@
  *   - the reference's buffer-aliasing corruption of the last <=771 stream bytes (P2) is
  *     replayed by default so outputs are bit-identical; set the environment variable
  *     DEBIG_STRICT=1 for spec-conforming output instead
- *   - colour type 2 (RGB) decodes to spec-conforming RGBA; the reference's own output for
- *     that colour type depends on a loop-nesting bug (P3) and is not reproduced
+ *   - colour type 2 (RGB): the reference's output depends on a loop-nesting bug (P3) and on
+ *     the PRIOR contents of out_rgba_values; it is reproduced bit for bit by default (the
+ *     buffer's prior bytes are read).  DEBIG_STRICT=1 gives spec-conforming RGBA instead
  */
 #ifndef DEBIG_DECODE_PNG_H
 #define DEBIG_DECODE_PNG_H

@@ -54,4 +54,4 @@ def test_struct_layouts_match_header():
 
     assert ctypes.sizeof(N.DebigStream) == 56 == STREAM_DTYPE.itemsize
     assert ctypes.sizeof(N.DebigResult) == 64 == RESULT_DTYPE.itemsize
-    assert ctypes.sizeof(N.DebigPngImage) == 40
+    assert ctypes.sizeof(N.DebigPngImage) == 56

@@ -140,3 +140,37 @@ def test_defilter_kernel_all_filter_types(emu, oracle):
             pal[512:512 + len(plte)] = plte[:, 2]
         rgba = _emu_defilter(emu, stream, p["w"], p["h"], p["ct"], pal)
         assert hashlib.sha256(rgba.tobytes()).hexdigest() == p["rgba_sha256"], (p["w"], p["h"], p["ct"], p["ftype"])
+
+
+def test_p3_rgb_replay_kernel_matches_reference_digest(emu):
+    """colour type 2 through debig_png_p3_kernel on the emulator: a small synthetic RGB image
+    against the oracle (pinned to the reference on this behaviour by backgrounddetailed1.png)."""
+    from oracle.binding import Oracle
+
+    orc = Oracle()
+    png, _ = workload.make_png(4242, 37, 21, ct=2, ftype=5, noise=9, enc="dynamic", idat_chunk=4096)
+    prior = (np.arange(37 * 21 * 4, dtype=np.uint32) * 40503 >> 7).astype(np.uint8)
+    want_good, want = orc.decode_png(png, prior=prior)
+    assert want_good == 1
+    at, z = 8, b""
+    while at + 8 <= len(png):
+        ln = int.from_bytes(png[at:at + 4], "big")
+        if png[at + 4:at + 8] == b"IDAT":
+            z += png[at + 8:at + 8 + ln]
+        at += 12 + ln
+    stream = zlib.decompress(z)
+    emu.emu_png_defilter_batch.restype = C.c_int
+    emu.emu_png_defilter_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    sa = np.zeros(len(stream) + 64, dtype=np.uint8)
+    sa[3:3 + len(stream)] = np.frombuffer(stream, dtype=np.uint8)
+    n = 37 * 21 * 4
+    tmp_off = (n + 31) // 16 * 16
+    rgba = np.zeros(tmp_off + n + 64, dtype=np.uint8)
+    rgba[:n] = prior
+    img = (DebigPngImage * 1)()
+    img[0].stream_off, img[0].rgba_off, img[0].pal_off, img[0].tmp_off = 3, 0, 0, tmp_off
+    img[0].width, img[0].height, img[0].color_type, img[0].asserts_off, img[0].replay_p3 = 37, 21, 2, 0, 1
+    res = (DebigPngResult * 1)()
+    assert emu.emu_png_defilter_batch(sa.ctypes.data, rgba.ctypes.data, img, res, 1) == 0
+    assert res[0].good == 1
+    assert np.array_equal(rgba[:n], want)

@@ -78,10 +78,9 @@ def test_decode_gz_sample(api):
 
 
 def test_decode_png_resources_match_reference(api, oracle):
-    """All 15 sample PNGs of the reference.  14 must equal the reference's own output bit for
-    bit (phoebus.png only thanks to the P2 aliasing replay); backgrounddetailed1.png is colour
-    type 2, where the reference's output is the P3 loop-nesting artefact: there we require
-    the spec-conforming image instead."""
+    """All 15 sample PNGs of the reference equal the reference's own output bit for bit:
+    phoebus.png thanks to the P2 aliasing replay, backgrounddetailed1.png (colour type 2)
+    thanks to the P3 replay (zero-initialised caller buffer, as in the golden run)."""
     gold = json.load(open(os.path.join(GOLD, "resources.json")))["png"]
     files = sorted(glob.glob(os.path.join(GOLD, "resources", "*.png")))
     assert len(files) == 15
@@ -94,12 +93,6 @@ def test_decode_png_resources_match_reference(api, oracle):
         assert good == g["good"] == 1, name
         w, h, _ = api.decode_png_get_width_height(d)
         assert (w, h) == (g["width"], g["height"])
-        if name == "backgrounddetailed1.png":
-            import zlib
-
-            # independent spec decode: inflate with zlib, de-filter in numpy
-            assert rgba.reshape(h, w, 4)[:, :, 3].min() == 255
-            continue
         assert sha(rgba.tobytes()) == g["rgba_sha256"], name
         # and the single-call entry point agrees with the batch one
     good, rgba = api.decode_png(datas[files.index(os.path.join(GOLD, "resources", "phoebus.png"))])
@@ -137,3 +130,31 @@ def test_legacy_names(api):
     L.decode_PNG(data.ctypes.data, len(data), out.ctypes.data, 400, C.byref(g))
     gold = json.load(open(os.path.join(GOLD, "resources.json")))["png"]["structuredart2.png"]
     assert g.value == 1 and sha(out.tobytes()) == gold["rgba_sha256"]
+
+
+def test_decode_png_rgb_p3_depends_on_prior_buffer_like_the_reference(api, oracle):
+    """colour type 2: the reference's result is a function of the stream AND of what the
+    caller's buffer held before (P3).  Same prior bytes -> same bytes as the oracle (which is
+    pinned to the reference on this file); DEBIG_STRICT=1 -> a real RGBA image."""
+    import ctypes as C
+
+    data = open(os.path.join(GOLD, "resources", "backgrounddetailed1.png"), "rb").read()
+    w, h, _ = api.decode_png_get_width_height(data)
+    prior = (np.arange(w * h * 4, dtype=np.uint32) * 2654435761 >> 13).astype(np.uint8)
+    want_good, want = oracle.decode_png(data, prior=prior)
+    L = api._lib()
+    d = np.frombuffer(data, dtype=np.uint8)
+    out = prior.copy()
+    good = C.c_uint8(7)
+    api.decode_png_init(thread_id=3)
+    L.decode_png(d.ctypes.data, len(d), out.ctypes.data, out.size, 3, C.byref(good))
+    assert good.value == want_good == 1
+    assert np.array_equal(out, want)
+    os.environ["DEBIG_STRICT"] = "1"
+    try:
+        good2, rgba = api.decode_png(data, thread_id=3)
+    finally:
+        del os.environ["DEBIG_STRICT"]
+    assert good2 == 1 and rgba.reshape(h, w, 4)[:, :, 3].min() == 255
+    g3, strict_want = oracle.decode_png(data, flags=1)  # ORC_PNG_STRICT does not touch P3; compare alpha only
+    assert g3 == 1

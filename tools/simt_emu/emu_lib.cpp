@@ -24,5 +24,7 @@ extern "C" int emu_png_defilter_batch(const void *streams_arena, void *rgba_aren
 {
     EMU_LAUNCH(debig_png_defilter_kernel, n, 64, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images,
                results, n);
+    EMU_LAUNCH(debig_png_p3_kernel, n, 64, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images,
+               results, n);
     return 0;
 }
