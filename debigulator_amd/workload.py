@@ -84,6 +84,14 @@ def make_stream(kind, index, size=65536):
     """cfg2 stream `index`: (raw deflate bytes, plain bytes).  stored -> random payload,
     fixed/dynamic -> text-like payload."""
     seed = SEED0 + index
+    if kind == "png":  # Paeth-filtered scanlines of a noisy RGBA image, dynamic Huffman (config 4's data)
+        w = 128
+        h = size // (4 * w + 1)
+        pix = np.zeros(w * h * 4, dtype=np.uint8)
+        lib().sg_payload_image(seed, w, h, 4, 24, pix.ctypes.data)
+        plain = np.zeros(size, dtype=np.uint8)
+        lib().sg_png_filter(pix.ctypes.data, w, h, 4, 4, plain.ctypes.data)
+        return encode("dynamic", plain), plain
     plain = payload("random" if kind == "stored" else "text", seed, size)
     return encode(kind, plain), plain
 
