@@ -75,8 +75,8 @@ def cpu_baseline(sample_fixed, sample_stored):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams", type=int, default=STREAMS_PER_KIND, help="streams per kind per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=64, help="streams per kind checked against the generator")
