@@ -71,7 +71,7 @@ extern emu_dim3 g_emu_blockIdx, g_emu_blockDim, g_emu_gridDim;
 struct emu_tid_proxy {
     struct X { operator unsigned() const { return g_emu.fibers[g_emu.cur].tid; } } x;
 };
-static emu_tid_proxy threadIdx;
+static emu_tid_proxy threadIdx __attribute__((unused));
 #define blockIdx g_emu_blockIdx
 #define blockDim g_emu_blockDim
 #define gridDim g_emu_gridDim
