@@ -162,3 +162,24 @@ def decode_gz(data):
         _libc.free(dd.data)
     _libc.free(C.cast(p, C.c_void_p))
     return good, out
+
+
+def decode_gz_batch(datas, out_caps, verify_trailer=True):
+    """n gzip members in one launch -> [(good, bytes, trailer_ok)]; trailer_ok = CRC-32 and ISIZE
+    of the member match the decompressed bytes (checked on the GPU; the reference never checks)."""
+    L = _lib()
+    L.debig_decode_gz_batch_ex.restype = C.c_int
+    L.debig_decode_gz_batch_ex.argtypes = [C.c_void_p] * 7 + [C.c_uint32]
+    n = len(datas)
+    ins = [_u8(d) for d in datas]
+    outs = [np.zeros(max(c, 1), dtype=np.uint8) for c in out_caps]
+    in_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in ins])
+    in_sizes = (C.c_uint32 * n)(*[len(a) for a in ins])
+    out_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in outs])
+    caps = (C.c_uint64 * n)(*out_caps)
+    sizes = (C.c_uint64 * n)()
+    goods = (C.c_uint32 * n)()
+    tok = (C.c_uint32 * n)()
+    rc = L.debig_decode_gz_batch_ex(in_ptrs, in_sizes, out_ptrs, caps, sizes, goods, tok if verify_trailer else None, n)
+    N.check(rc, "debig_decode_gz_batch_ex")
+    return [(goods[i], outs[i][: sizes[i]].tobytes(), tok[i]) for i in range(n)]

@@ -6,6 +6,7 @@
 
 #include "inflate_kernel.inc"
 #include "png_kernel.inc"
+#include "checksum_kernel.inc"
 
 // one wavefront per workgroup; enough workgroups in flight to fill 256 CUs x (LDS-limited)
 // resident waves, the rest grid-strides
@@ -36,7 +37,41 @@ static CodeTabs *fixed_tables(hipStream_t s)
     return p;
 }
 
+static CkTables *g_ck_tabs[64];
+static CkTables *checksum_tables(hipStream_t s)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (g_ck_tabs[dev]) return g_ck_tabs[dev];
+    CkTables *p = nullptr;
+    if (hipMalloc(&p, sizeof(CkTables)) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(debig_checksum_tables_kernel, dim3(1), dim3(CK_THREADS), 0, s, p);
+    if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+    g_ck_tabs[dev] = p;
+    return p;
+}
+
 extern "C" {
+
+int debig_hip_checksum_batch(const void *d_arena, const debig_span *d_spans, uint32_t *d_out,
+                             uint32_t n, uint32_t kind, void *hip_stream)
+{
+    if (n == 0) return 0;
+    CkTables *t = checksum_tables((hipStream_t)hip_stream);
+    if (!t) return (int)hipErrorOutOfMemory;
+    hipLaunchKernelGGL(debig_checksum_kernel, dim3(n), dim3(CK_THREADS), 0, (hipStream_t)hip_stream,
+                       (const uint8_t *)d_arena, d_spans, d_out, n, kind, t);
+    return (int)hipGetLastError();
+}
+
+int debig_hip_gather(const void *d_src_arena, void *d_dst_arena, const debig_copy *d_copies, uint32_t n,
+                     void *hip_stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(debig_gather_kernel, dim3(n), dim3(CK_THREADS), 0, (hipStream_t)hip_stream,
+                       (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, d_copies, n);
+    return (int)hipGetLastError();
+}
 
 int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d_streams,
                             debig_result *d_results, uint32_t n, void *hip_stream)

@@ -36,4 +36,8 @@ void debig_ctx_release(uint32_t thread_id)
     buf_free(&c->rgba);
     buf_free(&c->img);
     buf_free(&c->imgres);
+    buf_free(&c->files);
+    buf_free(&c->spans);
+    buf_free(&c->crcs);
+    buf_free(&c->copies);
 }

@@ -15,6 +15,7 @@ typedef struct debig_devbuf {
 
 typedef struct debig_ctx {
     debig_devbuf in, out, desc, res, rgba, img, imgres;
+    debig_devbuf files, spans, crcs, copies; /* PNG: whole files, chunk spans, their CRCs, IDAT gather list */
 } debig_ctx;
 
 debig_ctx *debig_ctx_get(uint32_t thread_id);

@@ -38,17 +38,31 @@ static int gz_locate(const uint8_t *in, uint32_t in_size, uint32_t *off, uint32_
     return 1;
 }
 
+int debig_inflate_batch_impl(uint8_t *const *outs, const uint64_t *out_caps, uint64_t *finals,
+                             const uint8_t *const *ins, const uint64_t *in_sizes, uint32_t *goods,
+                             uint32_t n, const uint32_t thread_id, uint64_t *dev_out_offs);
+
 DEBIG_API int debig_decode_gz_batch(const uint8_t *const *inputs, const uint32_t *input_sizes,
                                     uint8_t *const *outs, const uint64_t *out_caps, uint64_t *out_sizes,
                                     uint32_t *goods, uint32_t n)
 {
+    return debig_decode_gz_batch_ex(inputs, input_sizes, outs, out_caps, out_sizes, goods, NULL, n);
+}
+
+DEBIG_API int debig_decode_gz_batch_ex(const uint8_t *const *inputs, const uint32_t *input_sizes,
+                                       uint8_t *const *outs, const uint64_t *out_caps, uint64_t *out_sizes,
+                                       uint32_t *goods, uint32_t *trailer_ok, uint32_t n)
+{
     const uint8_t **ins = (const uint8_t **)calloc(n ? n : 1, sizeof(*ins));
+    uint64_t *offs = (uint64_t *)calloc(n ? n : 1, sizeof(uint64_t));
+    debig_span *spans = (debig_span *)calloc(n ? n : 1, sizeof(debig_span));
+    uint32_t *crcs = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
     uint64_t *lens = (uint64_t *)calloc(n ? n : 1, sizeof(uint64_t));
     uint64_t *fin = (uint64_t *)calloc(n ? n : 1, sizeof(uint64_t));
     uint64_t *caps = (uint64_t *)calloc(n ? n : 1, sizeof(uint64_t));
     uint8_t **dst = (uint8_t **)calloc(n ? n : 1, sizeof(*dst));
     int rc = 2;
-    if (!ins || !lens || !fin || !caps || !dst) goto done;
+    if (!ins || !lens || !fin || !caps || !dst || !offs || !spans || !crcs) goto done;
     for (uint32_t i = 0; i < n; i++) {
         uint32_t off = 0, len = 0;
         goods[i] = 0;
@@ -64,9 +78,37 @@ DEBIG_API int debig_decode_gz_batch(const uint8_t *const *inputs, const uint32_t
             dst[i] = outs[i];
         }
     }
-    rc = debig_inflate_batch(dst, caps, fin, ins, lens, goods, n, 0);
+    rc = debig_inflate_batch_impl(dst, caps, fin, ins, lens, goods, n, 0, offs);
     for (uint32_t i = 0; i < n; i++) out_sizes[i] = goods[i] ? fin[i] : 0;
+    if (!rc && trailer_ok) {
+        /* what the reference reads and ignores (src/decode_gz.c:281-297): CRC-32 and ISIZE of the
+         * member, checked against the decompressed bytes while they are still in HBM */
+        debig_ctx *c = debig_ctx_get(0);
+        for (uint32_t i = 0; i < n; i++) {
+            spans[i].off = offs[i];
+            spans[i].len = goods[i] ? fin[i] : 0;
+            trailer_ok[i] = 0;
+        }
+        if ((rc = debig_devbuf_reserve(&c->spans, (uint64_t)n * sizeof(debig_span))) == 0 &&
+            (rc = debig_devbuf_reserve(&c->crcs, (uint64_t)n * sizeof(uint32_t))) == 0 &&
+            (rc = debig_hip_memcpy_h2d(c->spans.ptr, spans, (uint64_t)n * sizeof(debig_span), NULL)) == 0 &&
+            (rc = debig_hip_checksum_batch(c->out.ptr, (const debig_span *)c->spans.ptr, (uint32_t *)c->crcs.ptr,
+                                           n, 0, NULL)) == 0 &&
+            (rc = debig_hip_memcpy_d2h(crcs, c->crcs.ptr, (uint64_t)n * sizeof(uint32_t), NULL)) == 0 &&
+            (rc = debig_hip_stream_sync(NULL)) == 0) {
+            for (uint32_t i = 0; i < n; i++) {
+                if (!goods[i] || !ins[i]) continue;
+                const uint8_t *t = ins[i] + lens[i]; /* the 8 trailer bytes follow the payload */
+                uint32_t crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+                uint32_t isz = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+                trailer_ok[i] = (crc == crcs[i]) && (isz == (uint32_t)fin[i]);
+            }
+        }
+    }
 done:
+    free(offs);
+    free(spans);
+    free(crcs);
     free(ins);
     free(lens);
     free(fin);

@@ -31,9 +31,22 @@ DEBIG_API void inflate_destroy(void (*free_funcptr)(void *), const uint32_t thre
     }
 }
 
+/* shared with debig_gz.c: same as debig_inflate_batch, and reports where each recipient lives
+ * in the context's device output arena (for checks that run on the device afterwards) */
+int debig_inflate_batch_impl(uint8_t *const *outs, const uint64_t *out_caps, uint64_t *finals,
+                             const uint8_t *const *ins, const uint64_t *in_sizes, uint32_t *goods,
+                             uint32_t n, const uint32_t thread_id, uint64_t *dev_out_offs);
+
 DEBIG_API int debig_inflate_batch(uint8_t *const *outs, const uint64_t *out_caps, uint64_t *finals,
                                   const uint8_t *const *ins, const uint64_t *in_sizes, uint32_t *goods,
                                   uint32_t n, const uint32_t thread_id)
+{
+    return debig_inflate_batch_impl(outs, out_caps, finals, ins, in_sizes, goods, n, thread_id, NULL);
+}
+
+int debig_inflate_batch_impl(uint8_t *const *outs, const uint64_t *out_caps, uint64_t *finals,
+                             const uint8_t *const *ins, const uint64_t *in_sizes, uint32_t *goods,
+                             uint32_t n, const uint32_t thread_id, uint64_t *dev_out_offs)
 {
     debig_ctx *c = debig_ctx_get(thread_id);
     for (uint32_t i = 0; i < n; i++) goods[i] = 0;
@@ -50,6 +63,7 @@ DEBIG_API int debig_inflate_batch(uint8_t *const *outs, const uint64_t *out_caps
         desc[i].in_off = in_total;
         desc[i].in_len = in_sizes[i];
         desc[i].out_off = out_total;
+        if (dev_out_offs) dev_out_offs[i] = out_total;
         desc[i].out_cap = out_caps[i];
         /* a stream that fails the size gates is never read or written by the kernel */
         int gated = out_caps[i] < in_sizes[i] || in_sizes[i] < 5;

@@ -2,10 +2,12 @@
  * Drop-in decode_png_init / decode_png_deinit / decode_png_get_width_height / decode_png
  * (reference src/decode_png.h:43-103, src/decode_png.c:562-1567) and their legacy names.
  *
- * Host side (plain C): signature, chunk walk, CRC-32, IHDR/PLTE/IDAT validation and IDAT
- * concatenation follow the reference's accept/reject rules; the two hot loops -- inflate
- * (src/inflate.c) and the per-byte de-filter / palette loops (src/decode_png.c:1381-1564) --
- * run on the GPU through debig_hip_inflate_batch / debig_hip_png_defilter_batch.
+ * Host side (plain C): only the METADATA walk -- signature, chunk headers, IHDR/PLTE/IDAT
+ * validation -- following the reference's accept/reject rules.  Everything that touches the
+ * bulk bytes runs on the GPU: chunk CRC-32 (debig_hip_checksum_batch, replaces update_crc
+ * src/decode_png.c:313-333), IDAT concatenation (debig_hip_gather, replaces :1285-1291),
+ * inflate (debig_hip_inflate_batch, replaces src/inflate.c) and the de-filter / palette
+ * loops (debig_hip_png_defilter_batch, replaces :1381-1564).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -25,23 +27,6 @@ typedef struct png_state {
 
 static png_state g_png[DEBIG_MAX_THREADS];
 
-static uint32_t g_crc_table[256];
-static int g_crc_ready;
-static void crc_init(void)
-{
-    for (uint32_t n = 0; n < 256; n++) {
-        uint32_t c = n;
-        for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
-        g_crc_table[n] = c;
-    }
-    g_crc_ready = 1;
-}
-static uint32_t crc_update(uint32_t crc, const uint8_t *p, uint64_t n)
-{
-    if (!g_crc_ready) crc_init();
-    for (uint64_t i = 0; i < n; i++) crc = g_crc_table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
-    return crc;
-}
 static uint32_t be32(const uint8_t *p)
 {
     return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
@@ -88,9 +73,51 @@ typedef struct png_parsed {
     int ok;            /* container accepted; inflate + de-filter still to run */
     uint32_t w, h, ct;
     uint64_t est;      /* recipient_size the reference hands to inflate: 4wh + h + 1 */
-    uint8_t *zdata;    /* concatenated IDAT payload minus the 2-byte zlib header (malloc'd) */
     uint64_t zsize;    /* compressed_input_size handed to inflate (payload - 4 Adler bytes) */
+    uint64_t packed;   /* total IDAT payload bytes (minus the 2-byte zlib header) */
+    /* chunk spans for the CRC kernel (type + data) with the CRC stored in the file, and the
+     * IDAT payload pieces for the gather kernel; offsets are relative to the file start */
+    uint32_t n_chunks, cap_chunks, n_idat, cap_idat;
+    struct png_chunk { uint64_t off, len; uint32_t crc; } *chunks;
+    struct png_piece { uint64_t off, len; } *idat;
 } png_parsed;
+
+static int push_chunk(png_parsed *r, uint64_t off, uint64_t len, uint32_t crc)
+{
+    if (r->n_chunks == r->cap_chunks) {
+        uint32_t cap = r->cap_chunks ? 2 * r->cap_chunks : 16;
+        void *p = realloc(r->chunks, cap * sizeof *r->chunks);
+        if (!p) return 0;
+        r->chunks = (struct png_chunk *)p;
+        r->cap_chunks = cap;
+    }
+    r->chunks[r->n_chunks].off = off;
+    r->chunks[r->n_chunks].len = len;
+    r->chunks[r->n_chunks].crc = crc;
+    r->n_chunks++;
+    return 1;
+}
+static int push_piece(png_parsed *r, uint64_t off, uint64_t len)
+{
+    if (r->n_idat == r->cap_idat) {
+        uint32_t cap = r->cap_idat ? 2 * r->cap_idat : 16;
+        void *p = realloc(r->idat, cap * sizeof *r->idat);
+        if (!p) return 0;
+        r->idat = (struct png_piece *)p;
+        r->cap_idat = cap;
+    }
+    r->idat[r->n_idat].off = off;
+    r->idat[r->n_idat].len = len;
+    r->n_idat++;
+    return 1;
+}
+static void parsed_free(png_parsed *r)
+{
+    free(r->chunks);
+    free(r->idat);
+    r->chunks = NULL;
+    r->idat = NULL;
+}
 
 /* The container walk restated (src/decode_png.c:730-1367): returns ok = 0 wherever the
  * reference sets *out_good = 0 before inflate runs.  size_left bookkeeping mirrors the
@@ -102,8 +129,6 @@ static void png_walk(png_state *st, const uint8_t *in, uint64_t in_size, uint64_
     if (in[1] != 'P' || in[2] != 'N' || in[3] != 'G') return;
     uint64_t at = 8, left = in_size - 8, packed = 0;
     int found_ihdr = 0, found_idat = 0, found_iend = 0, ready = 0;
-    uint8_t *z = (uint8_t *)malloc(in_size + 16);
-    if (!z) return;
     while (left >= 8 && !found_iend) {
         if (at + 8 > in_size) goto fail;
         uint32_t len = be32(in + at);
@@ -113,9 +138,7 @@ static void png_walk(png_state *st, const uint8_t *in, uint64_t in_size, uint64_
         int is_idat = !memcmp(type, "IDAT", 4);
         if (!is_idat && found_idat) ready = 1; /* the reference runs inflate here (:775-860) */
         if ((uint64_t)len >= left || at + (uint64_t)len + 4 > in_size) goto fail; /* :886-898 */
-        uint32_t crc = crc_update(0xffffffffu, type, 4);
-        if (len) crc = crc_update(crc, in + at, len);
-        crc ^= 0xffffffffu;
+        const uint64_t chunk_at = at - 4; /* the CRC covers type + data (:862-874) */
         if (!memcmp(type, "PLTE", 4)) { /* :900-950 */
             if (!found_ihdr) goto fail;
             if (r->ct == 0) goto fail;
@@ -161,7 +184,7 @@ static void png_walk(png_state *st, const uint8_t *in, uint64_t in_size, uint64_
                 if ((flg >> 5) & 1u) goto fail; /* FDICT */
             }
             if (at + (uint64_t)dlen > in_size) goto fail;
-            memcpy(z + packed, in + at, dlen);
+            if (dlen && !push_piece(r, at, dlen)) goto fail;
             packed += dlen;
             at += dlen;
             left -= dlen;
@@ -177,15 +200,16 @@ static void png_walk(png_state *st, const uint8_t *in, uint64_t in_size, uint64_
         uint32_t file_crc = be32(in + at);
         at += 4;
         left -= 4;
-        if (crc != file_crc) goto fail;
+        /* verified on the GPU together with every other chunk of the batch (:1333-1354) */
+        if (!push_chunk(r, chunk_at, (uint64_t)len + 4, file_crc)) goto fail;
     }
     if (!ready) goto fail; /* P6: inflate only runs when a non-IDAT chunk follows the IDATs */
-    r->zdata = z;
+    r->packed = packed;
     r->zsize = (uint64_t)(uint32_t)((uint32_t)packed - 4u); /* uint32 arithmetic as in :816 */
     r->ok = 1;
     return;
 fail:
-    free(z);
+    parsed_free(r);
     r->ok = 0;
 }
 
@@ -235,17 +259,76 @@ DEBIG_API int debig_decode_png_batch(const uint8_t *const *inputs, const uint64_
             if (P[i].ct == 2 && !strict) rgba_total += debig_align16(out_sizes[i]) + 16; /* P3 replay: second buffer */
         }
     }
-    if ((rc = debig_devbuf_reserve(&c->in, in_total + 64)) || (rc = debig_devbuf_reserve(&c->out, out_total + 64)) ||
+    /* ---- bulk bytes go to HBM once: whole files; chunk CRCs and the IDAT concatenation
+     *      happen there (the host has only looked at chunk headers) */
+    uint64_t files_total = 0;
+    uint32_t n_chunks = 0, n_pieces = 0;
+    uint64_t *file_off = (uint64_t *)calloc(n, sizeof(uint64_t));
+    if (!file_off) { rc = 2; goto done; }
+    for (uint32_t i = 0; i < n; i++) {
+        file_off[i] = files_total;
+        if (!P[i].ok) continue;
+        files_total += debig_align16(input_sizes[i]) + 16;
+        n_chunks += P[i].n_chunks;
+        n_pieces += P[i].n_idat;
+    }
+    debig_span *spans = (debig_span *)calloc(n_chunks ? n_chunks : 1, sizeof(debig_span));
+    uint32_t *crcs = (uint32_t *)calloc(n_chunks ? n_chunks : 1, sizeof(uint32_t));
+    debig_copy *copies = (debig_copy *)calloc(n_pieces ? n_pieces : 1, sizeof(debig_copy));
+    if (!spans || !crcs || !copies) { rc = 2; goto done_bulk; }
+    if ((rc = debig_devbuf_reserve(&c->files, files_total + 64)) ||
+        (rc = debig_devbuf_reserve(&c->spans, (uint64_t)(n_chunks + 1) * sizeof(debig_span))) ||
+        (rc = debig_devbuf_reserve(&c->crcs, (uint64_t)(n_chunks + 1) * sizeof(uint32_t))) ||
+        (rc = debig_devbuf_reserve(&c->copies, (uint64_t)(n_pieces + 1) * sizeof(debig_copy))) ||
+        (rc = debig_devbuf_reserve(&c->in, in_total + 64)) || (rc = debig_devbuf_reserve(&c->out, out_total + 64)) ||
         (rc = debig_devbuf_reserve(&c->rgba, rgba_total + 64)) ||
         (rc = debig_devbuf_reserve(&c->desc, (uint64_t)n * sizeof(debig_stream))) ||
         (rc = debig_devbuf_reserve(&c->res, (uint64_t)n * sizeof(debig_result))) ||
         (rc = debig_devbuf_reserve(&c->img, (uint64_t)n * sizeof(debig_png_image))) ||
         (rc = debig_devbuf_reserve(&c->imgres, (uint64_t)n * sizeof(debig_png_result))))
-        goto done;
-    for (uint32_t i = 0; i < n && !rc; i++) {
-        if (!P[i].ok || P[i].est < P[i].zsize || P[i].zsize < 5) continue; /* gated streams are never read */
-        rc = debig_hip_memcpy_h2d((uint8_t *)c->in.ptr + desc[i].in_off, P[i].zdata, P[i].zsize, NULL);
+        goto done_bulk;
+    {
+        uint32_t ci = 0, pi = 0;
+        for (uint32_t i = 0; i < n && !rc; i++) {
+            if (!P[i].ok) continue;
+            rc = debig_hip_memcpy_h2d((uint8_t *)c->files.ptr + file_off[i], inputs[i], input_sizes[i], NULL);
+            for (uint32_t k = 0; k < P[i].n_chunks; k++, ci++) {
+                spans[ci].off = file_off[i] + P[i].chunks[k].off;
+                spans[ci].len = P[i].chunks[k].len;
+            }
+            uint64_t pos = desc[i].in_off;
+            for (uint32_t k = 0; k < P[i].n_idat; k++, pi++) {
+                copies[pi].src_off = file_off[i] + P[i].idat[k].off;
+                copies[pi].dst_off = pos;
+                copies[pi].len = P[i].idat[k].len;
+                pos += P[i].idat[k].len;
+            }
+        }
+        if (!rc && n_chunks) {
+            rc = debig_hip_memcpy_h2d(c->spans.ptr, spans, (uint64_t)n_chunks * sizeof(debig_span), NULL);
+            if (!rc) rc = debig_hip_checksum_batch(c->files.ptr, (const debig_span *)c->spans.ptr,
+                                                   (uint32_t *)c->crcs.ptr, n_chunks, 0, NULL);
+            if (!rc) rc = debig_hip_memcpy_d2h(crcs, c->crcs.ptr, (uint64_t)n_chunks * sizeof(uint32_t), NULL);
+        }
+        if (!rc && n_pieces) {
+            rc = debig_hip_memcpy_h2d(c->copies.ptr, copies, (uint64_t)n_pieces * sizeof(debig_copy), NULL);
+            if (!rc) rc = debig_hip_gather(c->files.ptr, c->in.ptr, (const debig_copy *)c->copies.ptr, n_pieces, NULL);
+        }
+        if (!rc) rc = debig_hip_stream_sync(NULL);
+        /* a chunk whose CRC does not match fails its file (src/decode_png.c:1333-1354) */
+        ci = 0;
+        for (uint32_t i = 0; i < n && !rc; i++) {
+            if (!P[i].ok) continue;
+            for (uint32_t k = 0; k < P[i].n_chunks; k++, ci++)
+                if (crcs[ci] != P[i].chunks[k].crc) P[i].ok = 0;
+            if (!P[i].ok) { desc[i].in_len = 0; desc[i].out_cap = 0; } /* fails the inflate gates */
+        }
     }
+done_bulk:
+    free(spans);
+    free(crcs);
+    free(copies);
+    free(file_off);
     if (rc) goto done;
     if ((rc = debig_hip_memcpy_h2d(c->desc.ptr, desc, (uint64_t)n * sizeof(debig_stream), NULL))) goto done;
     if ((rc = debig_hip_inflate_batch(c->in.ptr, c->out.ptr, (const debig_stream *)c->desc.ptr,
@@ -303,7 +386,7 @@ done:
     if (rc)
         for (uint32_t i = 0; i < n; i++) goods[i] = 0;
     if (P)
-        for (uint32_t i = 0; i < n; i++) free(P[i].zdata);
+        for (uint32_t i = 0; i < n; i++) parsed_free(&P[i]);
     free(P);
     free(desc);
     free(res);

@@ -99,6 +99,30 @@ int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena
                                  const debig_png_image *d_images, debig_png_result *d_results,
                                  uint32_t n, void *hip_stream);
 
+/* A byte span of a device arena. */
+typedef struct debig_span {
+    uint64_t off;
+    uint64_t len;
+} debig_span;
+
+/* CRC-32 (kind 0; PNG chunk / gzip convention) or Adler-32 (kind 1; zlib) of n spans, one
+ * result word per span.  Replaces the per-byte update_crc loop the reference runs over every
+ * PNG chunk (src/decode_png.c:313-333, :862-874) and provides what it never verifies (gzip
+ * CRC32 trailer, zlib Adler-32: src/decode_gz.c:281-297, src/decode_png.c:393-395).
+ * Device pointers, asynchronous on hip_stream. */
+int debig_hip_checksum_batch(const void *d_arena, const debig_span *d_spans, uint32_t *d_out,
+                             uint32_t n, uint32_t kind, void *hip_stream);
+
+/* Copy n byte ranges between device arenas (any alignment): the IDAT concatenation of
+ * decode_png (src/decode_png.c:1285-1291) done in HBM. */
+typedef struct debig_copy {
+    uint64_t src_off;
+    uint64_t dst_off;
+    uint64_t len;
+} debig_copy;
+int debig_hip_gather(const void *d_src_arena, void *d_dst_arena, const debig_copy *d_copies,
+                     uint32_t n, void *hip_stream);
+
 /* plain device-to-device helpers used by the host layer (no torch needed) */
 int debig_hip_device_count(void);
 int debig_hip_set_device(int dev);

@@ -32,6 +32,13 @@ int debig_decode_gz_batch(const uint8_t *const *inputs, const uint32_t *input_si
                           uint8_t *const *outs, const uint64_t *out_caps, uint64_t *out_sizes,
                           uint32_t *goods, uint32_t n);
 
+/* Same, plus trailer_ok[i] = 1 when the member's CRC-32 and ISIZE trailer (which the
+ * reference reads and ignores, src/decode_gz.c:281-297) match the decompressed bytes; the
+ * CRC is computed on the GPU.  trailer_ok may be NULL. */
+int debig_decode_gz_batch_ex(const uint8_t *const *inputs, const uint32_t *input_sizes,
+                             uint8_t *const *outs, const uint64_t *out_caps, uint64_t *out_sizes,
+                             uint32_t *goods, uint32_t *trailer_ok, uint32_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -174,3 +174,25 @@ def test_p3_rgb_replay_kernel_matches_reference_digest(emu):
     assert emu.emu_png_defilter_batch(sa.ctypes.data, rgba.ctypes.data, img, res, 1) == 0
     assert res[0].good == 1
     assert np.array_equal(rgba[:n], want)
+
+
+def test_checksum_kernels_on_emulator(emu):
+    """CRC-32 / Adler-32 kernels (tile grid, polynomial combine, inverse power) vs zlib"""
+    import random
+
+    class Span(C.Structure):
+        _fields_ = [("off", C.c_uint64), ("len", C.c_uint64)]
+
+    emu.emu_checksum_batch.restype = C.c_int
+    emu.emu_checksum_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    rng = random.Random(9)
+    arena = np.frombuffer(bytes(rng.getrandbits(8) for _ in range(120000)), dtype=np.uint8).copy()
+    lens = [0, 1, 3, 4, 5, 16, 17, 64, 65, 1000, 16383, 16384, 16385, 50001]
+    spans = (Span * len(lens))()
+    for i, n in enumerate(lens):
+        spans[i].off, spans[i].len = rng.randrange(0, 60000), n
+    out = (C.c_uint32 * len(lens))()
+    for kind, fn in ((0, zlib.crc32), (1, zlib.adler32)):
+        assert emu.emu_checksum_batch(arena.ctypes.data, spans, out, len(lens), kind) == 0
+        for i, n in enumerate(lens):
+            assert out[i] == fn(arena[spans[i].off:spans[i].off + n].tobytes()), (kind, n)

@@ -158,3 +158,38 @@ def test_decode_png_rgb_p3_depends_on_prior_buffer_like_the_reference(api, oracl
     assert good2 == 1 and rgba.reshape(h, w, 4)[:, :, 3].min() == 255
     g3, strict_want = oracle.decode_png(data, flags=1)  # ORC_PNG_STRICT does not touch P3; compare alpha only
     assert g3 == 1
+
+
+def test_gzip_trailer_verification_on_gpu(api):
+    """extension beyond the reference (which reads the CRC32/ISIZE trailer and ignores it,
+    src/decode_gz.c:281-297): checked on the GPU against the decompressed bytes"""
+    from debigulator_amd import workload
+
+    members, plains = [], []
+    for i in range(6):
+        plain = workload.payload("text", 500 + i, 100000 + 777 * i)
+        members.append(bytearray(workload.gzip_member(workload.encode("dynamic", plain), plain)))
+        plains.append(plain.tobytes())
+    members[2][-6] ^= 0x40   # damage the stored CRC-32
+    members[4][-2] ^= 0x01   # damage ISIZE
+    res = api.decode_gz_batch([bytes(m) for m in members], [len(p) + 1 for p in plains])
+    for i, (good, out, tok) in enumerate(res):
+        assert good == 1 and out == plains[i]          # the reference's verdict: all fine
+        assert tok == (0 if i in (2, 4) else 1)
+
+
+def test_checksum_kernels_vs_zlib(gpu_device):
+    import zlib
+    import torch
+    from debigulator_amd.checksum import ADLER32, CRC32, DeviceChecksums
+
+    arena = torch.randint(0, 256, (3_000_000,), dtype=torch.uint8, device=gpu_device)
+    host = arena.cpu().numpy()
+    spans = [(0, 0), (5, 1), (6, 3), (7, 4), (100, 15), (101, 16), (102, 17), (1000, 16383), (20001, 16384),
+             (40003, 16385), (70000, 100000), (200001, 1234567), (1500000, 1499999)]
+    for kind, fn in ((CRC32, zlib.crc32), (ADLER32, zlib.adler32)):
+        ck = DeviceChecksums(arena, spans, kind)
+        ck.launch()
+        got = ck.results()
+        for (o, n), g in zip(spans, got):
+            assert g == fn(host[o:o + n].tobytes()), (kind, o, n)
