@@ -39,7 +39,7 @@ void emu_launch(emu_dim3 grid, emu_dim3 block, void (*entry)(void *), void *arg)
     (void)probe;
     for (unsigned b = 0; b < grid.x; b++) {
         g_emu_blockIdx = emu_dim3{b, 0, 0};
-        g_emu.arrived = 0;
+        for (int g = 0; g < 17; g++) g_emu.arrived[g] = 0;
         g_emu.waiting = 0;
         for (unsigned t = 0; t < block.x; t++) {
             emu_fiber &f = g_emu.fibers[t];

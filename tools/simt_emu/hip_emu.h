@@ -54,10 +54,11 @@ struct emu_state {
     std::vector<emu_fiber> fibers;
     unsigned cur;
     unsigned nthreads;
-    /* rendezvous */
+    /* rendezvous: index 0..15 = the wavefronts of the workgroup (wave collectives), 16 = the
+     * whole workgroup (__syncthreads) */
     uint64_t slot[1024];
-    unsigned arrived;
-    unsigned generation;
+    unsigned arrived[17];
+    unsigned generation[17];
     unsigned waiting;
     unsigned long long progress;
     void (*entry)(void *);
@@ -88,35 +89,61 @@ static inline void emu_yield()
 #endif
 }
 
-/* all threads of the workgroup exchange one 64-bit value */
-static inline void emu_rendezvous(uint64_t mine, uint64_t *all)
+/* rendezvous of one group of threads: group 16 = all threads of the workgroup, group w < 16 =
+ * the 64 threads of wavefront w.  Each exchanges one 64-bit value through slot[tid]. */
+static inline void emu_rendezvous_group(unsigned grp, unsigned nmembers, uint64_t mine)
 {
     unsigned me = g_emu.fibers[g_emu.cur].tid;
-    unsigned gen = g_emu.generation;
-    g_emu.slot[me] = mine;
-    g_emu.arrived++;
-    if (g_emu.arrived == g_emu.nthreads) {
-        g_emu.arrived = 0;
-        g_emu.generation++;
+    for (int phase = 0; phase < 2; phase++) {
+        unsigned gen = g_emu.generation[grp];
+        if (phase == 0) g_emu.slot[me] = mine;
+        g_emu.arrived[grp]++;
+        if (g_emu.arrived[grp] == nmembers) {
+            g_emu.arrived[grp] = 0;
+            g_emu.generation[grp]++;
+            g_emu.progress++;
+        } else {
+            g_emu.waiting++;
+            while (g_emu.generation[grp] == gen) emu_yield();
+            g_emu.waiting--;
+        }
+        /* between the two phases every member reads what it needs from slot[]; the second
+         * phase keeps anybody from overwriting slot[] before everyone has read it */
+        if (phase == 0) return;
+    }
+}
+static inline void emu_rendezvous_finish(unsigned grp, unsigned nmembers)
+{
+    unsigned gen = g_emu.generation[grp];
+    g_emu.arrived[grp]++;
+    if (g_emu.arrived[grp] == nmembers) {
+        g_emu.arrived[grp] = 0;
+        g_emu.generation[grp]++;
         g_emu.progress++;
     } else {
         g_emu.waiting++;
-        while (g_emu.generation == gen) emu_yield();
+        while (g_emu.generation[grp] == gen) emu_yield();
         g_emu.waiting--;
     }
+}
+
+/* all threads of the WORKGROUP exchange one 64-bit value */
+static inline void emu_rendezvous(uint64_t mine, uint64_t *all)
+{
+    emu_rendezvous_group(16, g_emu.nthreads, mine);
     for (unsigned i = 0; i < g_emu.nthreads; i++) all[i] = g_emu.slot[i];
-    /* second phase so nobody overwrites slot[] before everyone has read it */
-    gen = g_emu.generation;
-    g_emu.arrived++;
-    if (g_emu.arrived == g_emu.nthreads) {
-        g_emu.arrived = 0;
-        g_emu.generation++;
-        g_emu.progress++;
-    } else {
-        g_emu.waiting++;
-        while (g_emu.generation == gen) emu_yield();
-        g_emu.waiting--;
-    }
+    emu_rendezvous_finish(16, g_emu.nthreads);
+}
+
+/* the 64 threads of the calling thread's WAVEFRONT exchange one 64-bit value; all[0..63] */
+static inline void emu_wave_rendezvous(uint64_t mine, uint64_t *all)
+{
+    unsigned me = g_emu.fibers[g_emu.cur].tid;
+    unsigned w = me >> 6, base = me & ~63u;
+    unsigned members = g_emu.nthreads - base < 64 ? g_emu.nthreads - base : 64;
+    emu_rendezvous_group(w, members, mine);
+    for (unsigned i = 0; i < 64; i++) all[i] = (base + i < g_emu.nthreads) ? g_emu.slot[base + i] : 0;
+    emu_rendezvous_finish(w, members);
 }
 
 static inline void emu___syncthreads()
@@ -127,17 +154,16 @@ static inline void emu___syncthreads()
 
 template <typename T> static inline T emu_xchg(T v, int src_lane, bool clamp_self)
 {
-    uint64_t all[1024];
+    uint64_t all[64];
     uint64_t bits = 0;
     static_assert(sizeof(T) <= 8, "shfl of <= 8 bytes");
     memcpy(&bits, &v, sizeof(T));
-    emu_rendezvous(bits, all);
+    emu_wave_rendezvous(bits, all);
     unsigned me = g_emu.fibers[g_emu.cur].tid;
-    unsigned wave_base = me & ~63u;
     int lane = (int)(me & 63u);
     if (src_lane < 0 || src_lane > 63) src_lane = clamp_self ? lane : (src_lane & 63);
     T r;
-    memcpy(&r, &all[wave_base + (unsigned)src_lane], sizeof(T));
+    memcpy(&r, &all[(unsigned)src_lane], sizeof(T));
     return r;
 }
 template <typename T> static inline T emu___shfl(T v, int src) { return emu_xchg(v, src & 63, false); }
@@ -158,13 +184,11 @@ template <typename T> static inline T emu___shfl_xor(T v, int m)
 }
 static inline unsigned long long emu___ballot(int pred)
 {
-    uint64_t all[1024];
-    emu_rendezvous(pred ? 1 : 0, all);
-    unsigned me = g_emu.fibers[g_emu.cur].tid;
-    unsigned wave_base = me & ~63u;
+    uint64_t all[64];
+    emu_wave_rendezvous(pred ? 1 : 0, all);
     unsigned long long m = 0;
-    for (unsigned i = 0; i < 64 && wave_base + i < g_emu.nthreads; i++)
-        if (all[wave_base + i]) m |= 1ull << i;
+    for (unsigned i = 0; i < 64; i++)
+        if (all[i]) m |= 1ull << i;
     return m;
 }
 static inline int emu___any(int p) { return emu___ballot(p) != 0; }
@@ -191,9 +215,16 @@ template <typename T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o
 struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
 
+/* intra-wavefront barrier (on the GPU: LDS ordering inside one wave) */
+static inline void emu_wave_barrier()
+{
+    uint64_t all[64];
+    emu_wave_rendezvous(0, all);
+}
 extern int g_emu_line[1024];
 static inline void emu_mark(int line) { g_emu_line[g_emu.fibers[g_emu.cur].tid] = line; }
 #define __syncthreads() (emu_mark(__LINE__), emu___syncthreads())
+#define __wave_barrier() (emu_mark(__LINE__), emu_wave_barrier())
 #define __shfl(v, s) (emu_mark(__LINE__), emu___shfl((v), (s)))
 #define __shfl_up(v, d) (emu_mark(__LINE__), emu___shfl_up((v), (d)))
 #define __shfl_down(v, d) (emu_mark(__LINE__), emu___shfl_down((v), (d)))
