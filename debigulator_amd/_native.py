@@ -57,6 +57,8 @@ def lib():
     vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
     L.debig_hip_inflate_batch.restype = C.c_int
     L.debig_hip_inflate_batch.argtypes = [vp, vp, vp, vp, u32, vp]
+    L.debig_hip_inflate_batch_ex.restype = C.c_int
+    L.debig_hip_inflate_batch_ex.argtypes = [vp, vp, vp, vp, u32, u32, vp]
     L.debig_hip_png_defilter_batch.restype = C.c_int
     L.debig_hip_png_defilter_batch.argtypes = [vp, vp, vp, vp, u32, vp]
     L.debig_hip_device_count.restype = C.c_int

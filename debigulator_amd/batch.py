@@ -75,15 +75,17 @@ class DeviceBatch:
         in_arena, streams, out_bytes = pack_streams(raws, caps, **kw)
         return cls(in_arena, streams, out_bytes, device)
 
-    def launch(self, stream=None):
-        """Asynchronous: one kernel launch on `stream` (default: torch's current stream)."""
+    def launch(self, stream=None, waves_per_stream=0):
+        """Asynchronous: one kernel launch on `stream` (default: torch's current stream).
+        waves_per_stream: 1 (one wavefront per stream), 2 / 4 (one stream per workgroup of
+        that many wavefronts, for few large streams), 0 = library's choice from the batch size."""
         torch = self.torch
         if stream is None:
             stream = torch.cuda.current_stream(self.device)
-        rc = self.lib.debig_hip_inflate_batch(self.d_in.data_ptr(), self.d_out.data_ptr(),
-                                              self.d_streams.data_ptr(), self.d_results.data_ptr(),
-                                              self.n, C.c_void_p(stream.cuda_stream))
-        N.check(rc, "debig_hip_inflate_batch")
+        rc = self.lib.debig_hip_inflate_batch_ex(self.d_in.data_ptr(), self.d_out.data_ptr(),
+                                                 self.d_streams.data_ptr(), self.d_results.data_ptr(),
+                                                 self.n, waves_per_stream, C.c_void_p(stream.cuda_stream))
+        N.check(rc, "debig_hip_inflate_batch_ex")
 
     def results(self):
         self.torch.cuda.synchronize(self.device)

@@ -2,9 +2,11 @@
 // Built by debigulator_amd/build.py:  hipcc --offload-arch=gfx950 -O3 -shared -fPIC
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/debig_hip.h"
 
 #include "inflate_kernel.inc"
+#include "inflate_mw_kernel.inc"
 #include "png_kernel.inc"
 #include "checksum_kernel.inc"
 
@@ -73,16 +75,99 @@ int debig_hip_gather(const void *d_src_arena, void *d_dst_arena, const debig_cop
     return (int)hipGetLastError();
 }
 
+// Wavefronts per stream when the caller leaves the choice to the library.  The chip is full
+// at about 2048 resident decode wavefronts (256 CUs x 4 SIMDs x 2); with fewer streams than
+// that, several wavefronts share one stream (debig_inflate_mw_kernel).  Measured crossovers
+// (profiles/r01_mw_sweep.txt): n <= 512 -> 4, n <= 1024 -> 2, else 1.  The mixed modes are
+// never picked here: they only pay when FEW streams of a big batch are large, and stream
+// sizes live in device memory -- callers that know them ask for a mixed mode themselves
+// (csrc/host/debig_ctx.c: debig_pick_waves).
+static uint32_t auto_waves_per_stream(uint32_t n)
+{
+    // DEBIG_WAVES_PER_STREAM=1|2|4|0x41|0x42 overrides the choice (measurements, bisecting)
+    static int env_read = 0;
+    static uint32_t env_val = 0;
+    if (!env_read) {
+        const char *e = getenv("DEBIG_WAVES_PER_STREAM");
+        if (e && *e) env_val = (uint32_t)strtoul(e, nullptr, 0);
+        env_read = 1;
+    }
+    if (env_val) return env_val;
+    if (n <= 512u) return 4u;
+    if (n <= 1024u) return 2u;
+    return 1u;
+}
+
+static int launch_inflate(uint32_t width, uint32_t cls, hipStream_t s, const void *d_in, void *d_out,
+                          const debig_stream *d_streams, debig_result *d_results, uint32_t n, const CodeTabs *ft)
+{
+    const uint32_t grid = n; /* one workgroup per stream: the hardware scheduler balances lengths */
+    if (width == 1)
+        hipLaunchKernelGGL(debig_inflate_kernel, dim3(grid), dim3(64), 0, s, (const uint8_t *)d_in,
+                           (uint8_t *)d_out, d_streams, d_results, n, ft, cls);
+    else if (width == 2)
+        hipLaunchKernelGGL(debig_inflate_mw_kernel<2>, dim3(grid), dim3(128), 0, s, (const uint8_t *)d_in,
+                           (uint8_t *)d_out, d_streams, d_results, n, ft, cls);
+    else
+        hipLaunchKernelGGL(debig_inflate_mw_kernel<4>, dim3(grid), dim3(256), 0, s, (const uint8_t *)d_in,
+                           (uint8_t *)d_out, d_streams, d_results, n, ft, cls);
+    return (int)hipGetLastError();
+}
+
+// side stream + fork/join events for the two concurrent launches of a mixed-width batch
+struct SideLane {
+    hipStream_t stream;
+    hipEvent_t fork, join;
+    int ready;
+};
+static SideLane g_side[64];
+static SideLane *side_lane(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    SideLane *l = &g_side[dev];
+    if (l->ready) return l;
+    if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&l->fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&l->join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    l->ready = 1;
+    return l;
+}
+
+int debig_hip_inflate_batch_ex(const void *d_in, void *d_out, const debig_stream *d_streams,
+                               debig_result *d_results, uint32_t n, uint32_t waves_per_stream,
+                               void *hip_stream)
+{
+    if (n == 0) return 0;
+    if (waves_per_stream == 0) waves_per_stream = auto_waves_per_stream(n);
+    const int mixed = waves_per_stream == DEBIG_WAVES_LARGE4_SMALL1 || waves_per_stream == DEBIG_WAVES_LARGE4_SMALL2;
+    if (!mixed && waves_per_stream != 1 && waves_per_stream != 2 && waves_per_stream != 4)
+        return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)hip_stream;
+    CodeTabs *ft = fixed_tables(s);
+    if (!ft) return (int)hipErrorOutOfMemory;
+    if (!mixed) return launch_inflate(waves_per_stream, DEBIG_CLASS_ALL, s, d_in, d_out, d_streams, d_results, n, ft);
+
+    // large streams 4-wide on the side stream, small ones beside them on the caller's stream;
+    // the caller's stream continues only when both are done
+    SideLane *l = side_lane();
+    if (!l) return (int)hipErrorOutOfMemory;
+    hipError_t e;
+    if ((e = hipEventRecord(l->fork, s)) != hipSuccess) return (int)e;
+    if ((e = hipStreamWaitEvent(l->stream, l->fork, 0)) != hipSuccess) return (int)e;
+    int rc = launch_inflate(4, DEBIG_CLASS_LARGE, l->stream, d_in, d_out, d_streams, d_results, n, ft);
+    if (rc) return rc;
+    if ((e = hipEventRecord(l->join, l->stream)) != hipSuccess) return (int)e;
+    rc = launch_inflate(waves_per_stream & 15u, DEBIG_CLASS_SMALL, s, d_in, d_out, d_streams, d_results, n, ft);
+    if (rc) return rc;
+    if ((e = hipStreamWaitEvent(s, l->join, 0)) != hipSuccess) return (int)e;
+    return 0;
+}
+
 int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d_streams,
                             debig_result *d_results, uint32_t n, void *hip_stream)
 {
-    if (n == 0) return 0;
-    CodeTabs *ft = fixed_tables((hipStream_t)hip_stream);
-    if (!ft) return (int)hipErrorOutOfMemory;
-    uint32_t grid = n; /* one workgroup per stream: the hardware scheduler balances lengths */
-    hipLaunchKernelGGL(debig_inflate_kernel, dim3(grid), dim3(64), 0, (hipStream_t)hip_stream,
-                       (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, d_results, n, ft);
-    return (int)hipGetLastError();
+    return debig_hip_inflate_batch_ex(d_in, d_out, d_streams, d_results, n, 0, hip_stream);
 }
 
 int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena,

@@ -72,6 +72,28 @@ typedef struct debig_result {
 int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d_streams,
                             debig_result *d_results, uint32_t n, void *hip_stream);
 
+/* Same, choosing how many 64-lane wavefronts cooperate on ONE stream:
+ *   1          one wavefront per stream (best for many thousands of streams)
+ *   2, 4       one stream per workgroup of that many wavefronts (best for a few large
+ *              streams, e.g. big PNG images)
+ *   DEBIG_WAVES_LARGE4_SMALL1 / _SMALL2
+ *              by stream: large ones (>= 256 KiB of input or >= 1 MiB of recipient) 4-wide,
+ *              the others 1- or 2-wide, as two launches that run side by side (an internal
+ *              HIP stream; hip_stream continues only after both)
+ *   0          the library picks from n: n <= 512: 4; n <= 1024: 2; else 1 (never a mixed
+ *              mode: stream sizes are in device memory).  debig_hip_inflate_batch does this.
+ *              The environment variable DEBIG_WAVES_PER_STREAM (1, 2, 4, 0x41, 0x42)
+ *              replaces this choice, for measurements.
+ * Results are identical for every choice.  Any other value: hipErrorInvalidValue. */
+#define DEBIG_LARGE_IN_BYTES (256u << 10)  /* a stream is "large" from this much input ...   */
+#define DEBIG_LARGE_OUT_BYTES (1u << 20)   /* ... or this much recipient (out_cap)            */
+#define DEBIG_WAVES_AUTO 0u
+#define DEBIG_WAVES_LARGE4_SMALL1 0x41u
+#define DEBIG_WAVES_LARGE4_SMALL2 0x42u
+int debig_hip_inflate_batch_ex(const void *d_in, void *d_out, const debig_stream *d_streams,
+                               debig_result *d_results, uint32_t n, uint32_t waves_per_stream,
+                               void *hip_stream);
+
 /* One image for the de-filter kernel: the inflated scanline stream (filter byte
  * + w*bpp bytes per row) -> 4-channel RGBA. */
 typedef struct debig_png_image {

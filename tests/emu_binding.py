@@ -28,6 +28,12 @@ def load_emu(asan=False):
     L = C.CDLL(os.path.join(EMU_DIR, name))
     L.emu_inflate_batch.restype = C.c_int
     L.emu_inflate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    L.emu_inflate_batch_cls.restype = C.c_int
+    L.emu_inflate_batch_cls.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                        C.c_uint32, C.c_uint32]
+    L.emu_inflate_mw_batch.restype = C.c_int
+    L.emu_inflate_mw_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                       C.c_uint32]
     return L
 
 
@@ -60,9 +66,21 @@ def layout_batch(raws, caps, in_misalign=0, out_misalign=0, p2=None):
     return in_arena, out_arena, streams, results, offs
 
 
-def emu_inflate(L, raws, caps, grid=0, **kw):
+def emu_inflate(L, raws, caps, grid=0, nw=1, classes=None, **kw):
+    """nw = 1: debig_inflate_kernel; nw = 2 / 4: debig_inflate_mw_kernel<nw> (one stream per
+    workgroup of nw wavefronts).  classes = [(nw, cls), ...]: one launch per entry, each
+    restricted to a stream class (1 small, 2 large), like the shim's mixed-width mode."""
     in_arena, out_arena, streams, results, offs = layout_batch(raws, caps, **kw)
-    rc = L.emu_inflate_batch(in_arena.ctypes.data, out_arena.ctypes.data, streams, results, len(raws), grid)
+    if classes is not None:
+        rc = 0
+        for w, cls in classes:
+            rc |= L.emu_inflate_batch_cls(in_arena.ctypes.data, out_arena.ctypes.data, streams, results,
+                                          len(raws), grid, w, cls)
+    elif nw == 1:
+        rc = L.emu_inflate_batch(in_arena.ctypes.data, out_arena.ctypes.data, streams, results, len(raws), grid)
+    else:
+        rc = L.emu_inflate_mw_batch(in_arena.ctypes.data, out_arena.ctypes.data, streams, results, len(raws),
+                                    grid, nw)
     assert rc == 0
     outs = []
     for i, (_, oo) in enumerate(offs):

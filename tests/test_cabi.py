@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(native_lib):
     # parameter names are not functions
     declared -= {"inflate", "malloc_funcptr", "arg_memset_func", "arg_memcpy_func", "arg_free_funcptr",
                  "arg_memset_funcptr", "free_funcptr"}
-    assert {"debig_hip_inflate_batch", "debig_hip_png_defilter_batch", "debig_inflate", "inflate_init",
+    assert {"debig_hip_inflate_batch", "debig_hip_inflate_batch_ex", "debig_hip_png_defilter_batch", "debig_inflate", "inflate_init",
             "inflate_destroy", "decode_png", "decode_png_init", "decode_png_deinit",
             "decode_png_get_width_height", "decode_gz", "init_decode_gz", "decode_PNG", "init_PNG_decoder",
             "get_PNG_width_height", "debig_inflate_batch", "debig_decode_png_batch",

@@ -24,12 +24,14 @@ def emu():
     return eb.load_emu()
 
 
-def test_known_answers_and_corpus(emu):
+# wavefronts per stream: 1 = debig_inflate_kernel, 2 / 4 = debig_inflate_mw_kernel<NW>
+@pytest.mark.parametrize("nw", [1, 2, 4])
+def test_known_answers_and_corpus(emu, nw):
     items = json.load(open(os.path.join(GOLD, "kat.json")))
-    items += json.load(open(os.path.join(GOLD, "corpus_zlib.json")))[:80]
+    items += json.load(open(os.path.join(GOLD, "corpus_zlib.json")))[:80 if nw == 1 else 40]
     raws = [bytes.fromhex(k["raw_hex"]) for k in items]
     caps = [k["recipient_size"] for k in items]
-    outs, arena, offs = eb.emu_inflate(emu, raws, caps, in_misalign=3, out_misalign=5)
+    outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, in_misalign=3, out_misalign=5)
     for k, (good, final, out, r) in zip(items, outs):
         assert good == k["good"] and final == k["final"], k.get("name")
         want = k.get("out_hex")
@@ -53,10 +55,38 @@ def test_cfg2_streams(emu, oracle, kind):
             assert r.n_windows > 0 and r.n_rounds / r.n_windows < 6  # speculation converges fast
 
 
-def test_corrupt_streams_agree_with_oracle(emu, oracle):
+def test_multi_wavefront_kernel_crosses_windows_and_tiles(emu):
+    """One 64 KiB dynamic-Huffman stream through the 4-wavefront kernel: several 17 KiB input
+    windows, the 16 KiB output tile rolls over, matches are resolved by all wavefronts."""
+    raw, plain = workload.make_stream("dynamic", 5, 65536)
+    outs, _, _ = eb.emu_inflate(emu, [raw], [65537], nw=4, out_misalign=9)
+    good, final, out, r = outs[0]
+    assert (good, final) == (1, 65536) and out == plain.tobytes()
+    assert r.n_windows >= 2
+
+
+def test_mixed_width_launches_partition_the_batch(emu, oracle):
+    """debig_hip_inflate_batch_ex's mixed mode: the 4-wavefront kernel takes the large class
+    (>= 256 KiB input or >= 1 MiB recipient), the 1-wavefront kernel the rest; together they
+    decode every stream exactly once."""
+    rng = random.Random(9)
+    raws, caps = [], []
+    for it in range(10):
+        data = bytes(rng.choice(b"abcdefgh ") for _ in range(rng.randint(100, 6000)))
+        raws.append(zlib.compress(data, 6)[2:-4])
+        caps.append((1 << 20) + it if it % 2 else len(data) + 7)  # odd ones are "large" by recipient
+    exp = [oracle.inflate(r, c) for r, c in zip(raws, caps)]
+    outs, _, _ = eb.emu_inflate(emu, raws, caps, classes=[(4, 2), (1, 1)])
+    assert [(g, f, o) for g, f, o, _ in outs] == [tuple(e) for e in exp]
+    only_large, _, _ = eb.emu_inflate(emu, raws, caps, classes=[(4, 2)])
+    assert [r.final_set for _, _, _, r in only_large] == [it % 2 for it in range(10)]
+
+
+@pytest.mark.parametrize("nw", [1, 4])
+def test_corrupt_streams_agree_with_oracle(emu, oracle, nw):
     rng = random.Random(4)
     raws, caps = [], []
-    for it in range(60):
+    for it in range(60 if nw == 1 else 30):
         data = bytes(rng.choice(b"abcdefgh ") for _ in range(rng.randint(50, 3000)))
         raw = bytearray(zlib.compress(data, rng.choice([1, 6, 9]))[2:-4])
         if rng.random() < 0.5:
@@ -65,7 +95,7 @@ def test_corrupt_streams_agree_with_oracle(emu, oracle):
             raw[rng.randrange(len(raw))] ^= 1 << rng.randrange(8)
         raws.append(bytes(raw))
         caps.append(len(data) * 4 + 64)
-    outs, arena, offs = eb.emu_inflate(emu, raws, caps)
+    outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw)
     for raw, cap, (good, final, out, r) in zip(raws, caps, outs):
         eg, ef, eo, st = oracle.inflate(raw, cap, want_stats=True)
         if st.ub_flags & (0x10 | 0x02):
@@ -73,7 +103,8 @@ def test_corrupt_streams_agree_with_oracle(emu, oracle):
         assert (good, final, out) == (eg, ef, eo)
 
 
-def test_p2_aliasing_replay_matches_reference_digest(emu):
+@pytest.mark.parametrize("nw", [1, 4])
+def test_p2_aliasing_replay_matches_reference_digest(emu, nw):
     """phoebus.png: the inflate kernel with the decode_png aliasing parameters + the
     de-filter kernel reproduce the reference's (corrupted-tail) output."""
     gold = json.load(open(os.path.join(GOLD, "resources.json")))["png"]["phoebus.png"]
@@ -89,7 +120,7 @@ def test_p2_aliasing_replay_matches_reference_digest(emu):
     raw = z[2:-4]
     est = 4 * w * h + h + 1
     s0 = est - 772 + ((16 - (est & 15)) & 15)
-    outs, arena, offs = eb.emu_inflate(emu, [raw], [est], p2=[(s0, est)])
+    outs, arena, offs = eb.emu_inflate(emu, [raw], [est], nw=nw, p2=[(s0, est)])
     good, final, stream, r = outs[0]
     assert good == 1 and final == est - 1
     rgba = _emu_defilter(emu, stream, w, h, 6)

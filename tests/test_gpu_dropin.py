@@ -42,6 +42,23 @@ def test_inflate_corpus_vs_reference_digests(api):
     assert sum(c["truncated_by_tail_rule"] for c in corpus) > 0  # the Q2 tail rule is exercised
 
 
+def test_inflate_batch_big_batch_with_a_few_large_streams(api):
+    """debig_inflate_batch picks the kernel width from the batch (csrc/host/debig_ctx.h:
+    debig_pick_waves): more than 1024 streams of which a few are large runs those 4-wide next
+    to the small ones.  Whatever it picks, every stream must come back exact."""
+    from debigulator_amd import workload
+
+    small = workload.make_streams("dynamic", 16, 20000)
+    large = workload.make_streams("fixed", 2, 2 << 20)
+    pairs = [small[i % 16] for i in range(1100)]
+    pairs[7], pairs[600], pairs[1099] = large[0], large[1], large[0]
+    res = api.inflate_batch([p[0] for p in pairs], [len(p[1]) + 1 for p in pairs])
+    for i, ((good, final, out), (_, plain)) in enumerate(zip(res, pairs)):
+        assert good == 1 and final == len(plain), i
+        if i % 97 == 0 or i in (7, 600, 1099):
+            assert out == plain.tobytes(), i
+
+
 def test_inflate_argument_gates(api):
     import ctypes as C
     from debigulator_amd import _native as N

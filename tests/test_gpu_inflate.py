@@ -46,26 +46,36 @@ def _payload(rng, n, kind):
     return (bytes(rng.getrandbits(8) for _ in range(rng.randint(1, 40))) * (n // 2 + 1))[:n]
 
 
-def _check(oracle, gpu_device, raws, caps, **kw):
+# wavefronts per stream: debig_inflate_kernel, debig_inflate_mw_kernel<2>, <4>, and the two
+# mixed modes (large streams 4-wide beside small ones 1- / 2-wide, include/debig_hip.h)
+WIDTHS = (1, 2, 4, 0x41, 0x42)
+
+
+def _check(oracle, gpu_device, raws, caps, widths=WIDTHS, **kw):
+    """Every kernel width must give the oracle's answer (include/debig_hip.h:
+    debig_hip_inflate_batch_ex -- results are identical for every choice)."""
     exp = [oracle.inflate(r, c, want_stats=True) for r, c in zip(raws, caps)]
     b = DeviceBatch.from_streams(raws, caps, device=gpu_device, **kw)
-    b.launch()
-    res = b.results()
-    host = b.outputs_host()
-    for i, (g, f, o, st) in enumerate(exp):
-        cap = int(b.streams_host[i]["out_cap"])
-        off = int(b.streams_host[i]["out_off"])
-        # nothing beyond recipient_size may be touched, whatever the input
-        assert not host[off + cap:off + cap + 32].any(), f"stream {i}: wrote past recipient_size"
-        if st.ub_flags & UB_EXCLUDED:
-            continue  # the reference itself is in undefined behaviour here
-        assert res[i]["good"] == g, (i, res[i], f)
-        if f is None:
-            assert res[i]["final_set"] == 0
-            continue
-        assert res[i]["final_set"] == 1
-        assert int(res[i]["final_size"]) == f, (i, res[i], f)
-        assert host[off:off + f].tobytes() == o, f"stream {i}: bytes differ"
+    for width in widths:
+        b.d_out.zero_()
+        b.d_results.zero_()
+        b.launch(waves_per_stream=width)
+        res = b.results()
+        host = b.outputs_host()
+        for i, (g, f, o, st) in enumerate(exp):
+            cap = int(b.streams_host[i]["out_cap"])
+            off = int(b.streams_host[i]["out_off"])
+            # nothing beyond recipient_size may be touched, whatever the input
+            assert not host[off + cap:off + cap + 32].any(), f"width {width} stream {i}: wrote past recipient_size"
+            if st.ub_flags & UB_EXCLUDED:
+                continue  # the reference itself is in undefined behaviour here (SURVEY.md 8a)
+            assert res[i]["good"] == g, (width, i, res[i], f)
+            if f is None:
+                assert res[i]["final_set"] == 0
+                continue
+            assert res[i]["final_set"] == 1
+            assert int(res[i]["final_size"]) == f, (width, i, res[i], f)
+            assert host[off:off + f].tobytes() == o, f"width {width} stream {i}: bytes differ"
 
 
 def test_zlib_streams_all_strategies(oracle, gpu_device):
@@ -163,6 +173,81 @@ def test_roundtrip_full_size_property(gpu_device):
     for i, (_, plain) in enumerate(pairs):
         off = int(b.streams_host[i]["out_off"])
         assert np.array_equal(host[off:off + 65536], plain), i
+
+
+def test_large_streams_every_width(gpu_device):
+    """Few large streams (the decode_png config 4 regime): 4 MiB each, text-like fixed and
+    dynamic Huffman and Paeth-filtered image rows; every kernel width must return the
+    generator's plain bytes (size-independent round-trip property; the oracle is not
+    needed at this size)."""
+    size = 4 << 20
+    pairs = []
+    for kind in ("fixed", "dynamic", "png"):
+        pairs += workload.make_streams(kind, 2, size)
+    pairs += workload.make_streams("dynamic", 6, 40000)  # the small class of the mixed modes
+    raws = [p[0] for p in pairs]
+    caps = [len(p[1]) + 1 for p in pairs]
+    b = DeviceBatch.from_streams(raws, caps, device=gpu_device, out_skew=5)
+    for width in WIDTHS:
+        b.d_out.zero_()
+        b.d_results.zero_()
+        b.launch(waves_per_stream=width)
+        res = b.results()
+        assert (res["good"] == 1).all(), (width, res)
+        for i, (_, plain) in enumerate(pairs):
+            assert b.output(i, res) == plain.tobytes(), (width, i)
+
+
+def test_p2_aliasing_replay_every_width(gpu_device):
+    """decode_png's buffer-aliasing replay (parameters p2_s0 / p2_est of
+    debig_stream) is part of the inflate kernel: all widths must produce the same, replayed,
+    stream.  The 4-wavefront result is pinned to the reference's digest by
+    test_gpu_dropin.py (decode_png of one file runs that width)."""
+    import os
+
+    gold = os.path.join(os.path.dirname(__file__), "golden", "resources")
+    streams = {}
+    for name in sorted(os.listdir(gold)):
+        if not name.endswith(".png"):
+            continue
+        data = open(os.path.join(gold, name), "rb").read()
+        w = int.from_bytes(data[16:20], "big")
+        h = int.from_bytes(data[20:24], "big")
+        at, z = 8, b""
+        while at + 8 <= len(data):
+            ln = int.from_bytes(data[at:at + 4], "big")
+            if data[at + 4:at + 8] == b"IDAT":
+                z += data[at + 8:at + 8 + ln]
+            at += 12 + ln
+        if len(z) < 16:
+            continue
+        est = 4 * w * h + h + 1
+        s0 = est - 772 + ((16 - (est & 15)) & 15)
+        streams[name] = (z[2:-4], est, s0)
+    assert len(streams) >= 8
+    names = sorted(streams)
+    raws = [streams[n][0] for n in names]
+    caps = [max(streams[n][1], len(streams[n][0])) for n in names]
+    p2 = [(streams[n][2], streams[n][1]) for n in names]
+    b = DeviceBatch.from_streams(raws, caps, device=gpu_device, p2=p2)
+    got = {}
+    for width in WIDTHS:
+        b.d_out.zero_()
+        b.d_results.zero_()
+        b.launch(waves_per_stream=width)
+        res = b.results()
+        got[width] = [(int(res[i]["good"]), int(res[i]["final_size"]), b.output(i, res)) for i in range(len(names))]
+    assert any(g for g, _, _ in got[1])
+    for width in WIDTHS[1:]:
+        for i, n in enumerate(names):
+            assert got[width][i] == got[1][i], (width, n)
+
+
+def test_invalid_width_is_rejected(gpu_device):
+    pairs = workload.make_streams("fixed", 1, 4096)
+    b = DeviceBatch.from_streams([pairs[0][0]], [8192], device=gpu_device)
+    with pytest.raises(Exception):
+        b.launch(waves_per_stream=3)
 
 
 def test_mass_corruption_stays_in_bounds_and_agrees(oracle, gpu_device):

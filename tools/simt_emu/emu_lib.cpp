@@ -4,11 +4,28 @@
 #include "hip_emu.h"
 #include "../../include/debig_hip.h"
 #include "../../debigulator_amd/csrc/inflate_kernel.inc"
+#include "../../debigulator_amd/csrc/inflate_mw_kernel.inc"
 #include "../../debigulator_amd/csrc/png_kernel.inc"
 #include "../../debigulator_amd/csrc/checksum_kernel.inc"
 
+/* cls: DEBIG_CLASS_ALL / _SMALL / _LARGE (streams outside the class are left untouched) */
+extern "C" int emu_inflate_batch_cls(const void *in, void *out, const debig_stream *streams,
+                                     debig_result *results, uint32_t n, uint32_t grid, uint32_t nw, uint32_t cls);
+
 extern "C" int emu_inflate_batch(const void *in, void *out, const debig_stream *streams,
                                  debig_result *results, uint32_t n, uint32_t grid)
+{
+    return emu_inflate_batch_cls(in, out, streams, results, n, grid, 1, 0);
+}
+
+extern "C" int emu_inflate_mw_batch(const void *in, void *out, const debig_stream *streams,
+                                    debig_result *results, uint32_t n, uint32_t grid, uint32_t nw)
+{
+    return emu_inflate_batch_cls(in, out, streams, results, n, grid, nw, 0);
+}
+
+static int emu_inflate_1(const void *in, void *out, const debig_stream *streams,
+                                 debig_result *results, uint32_t n, uint32_t grid, uint32_t cls)
 {
     if (grid == 0 || grid > n) grid = n;
     static CodeTabs *ft = nullptr;
@@ -16,7 +33,27 @@ extern "C" int emu_inflate_batch(const void *in, void *out, const debig_stream *
         ft = (CodeTabs *)calloc(1, sizeof(CodeTabs));
         EMU_LAUNCH(debig_fixed_tables_kernel, 1, 64, ft);
     }
-    EMU_LAUNCH(debig_inflate_kernel, grid, 64, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft);
+    EMU_LAUNCH(debig_inflate_kernel, grid, 64, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft, cls);
+    return 0;
+}
+
+/* the multi-wavefront-per-stream kernel: nw = 2 or 4 wavefronts per workgroup */
+extern "C" int emu_inflate_batch_cls(const void *in, void *out, const debig_stream *streams,
+                                     debig_result *results, uint32_t n, uint32_t grid, uint32_t nw, uint32_t cls)
+{
+    if (nw == 1) return emu_inflate_1(in, out, streams, results, n, grid, cls);
+    if (grid == 0 || grid > n) grid = n;
+    static CodeTabs *ft = nullptr;
+    if (!ft) {
+        ft = (CodeTabs *)calloc(1, sizeof(CodeTabs));
+        EMU_LAUNCH(debig_fixed_tables_kernel, 1, 64, ft);
+    }
+    if (nw == 2)
+        EMU_LAUNCH(debig_inflate_mw_kernel<2>, grid, 128, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft, cls);
+    else if (nw == 4)
+        EMU_LAUNCH(debig_inflate_mw_kernel<4>, grid, 256, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft, cls);
+    else
+        return -1;
     return 0;
 }
 
