@@ -82,6 +82,16 @@ class DevicePngBatch:
     def launch_inflate_only(self, stream=None):
         self.inflate.launch(stream)
 
+    def launch_defilter_only(self, stream=None):
+        """De-filter the streams a previous launch() left in HBM (timing of that kernel alone)."""
+        torch = self.torch
+        if stream is None:
+            stream = torch.cuda.current_stream(self.inflate.device)
+        rc = self.lib.debig_hip_png_defilter_batch(self.inflate.d_out.data_ptr(), self.d_rgba.data_ptr(),
+                                                   self.d_img.data_ptr(), self.d_ires.data_ptr(), self.n,
+                                                   C.c_void_p(stream.cuda_stream))
+        N.check(rc, "debig_hip_png_defilter_batch")
+
     def results(self):
         self.torch.cuda.synchronize()
         ires = self.d_ires.cpu().numpy().view(np.dtype([("good", "<u4"), ("bad_row", "<u4")]))

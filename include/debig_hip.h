@@ -117,6 +117,9 @@ typedef struct debig_png_result {
     uint32_t bad_row; /* first row whose filter byte was > 4 (when good == 0) */
 } debig_png_result;
 
+/* De-filter n inflated scanline streams into RGBA (device pointers, asynchronous on
+ * hip_stream).  d_streams_arena must stay readable for 16 bytes past the end of every
+ * stream (h * (w * bpp + 1) bytes): rows are fetched as aligned 16-byte pieces. */
 int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena,
                                  const debig_png_image *d_images, debig_png_result *d_results,
                                  uint32_t n, void *hip_stream);

@@ -173,6 +173,57 @@ def test_defilter_kernel_all_filter_types(emu, oracle):
         assert hashlib.sha256(rgba.tobytes()).hexdigest() == p["rgba_sha256"], (p["w"], p["h"], p["ct"], p["ftype"])
 
 
+def _spec_defilter(stream, w, h, bpp):
+    """PNG specification de-filter (what src/decode_png.c:1430-1507 computes for bpp 4 and 1),
+    written independently of the kernel: bytes of the de-filtered rows, [h, w*bpp]."""
+    rowb = w * bpp
+    out = np.zeros((h, rowb), dtype=np.uint8)
+    for y in range(h):
+        ft = stream[y * (rowb + 1)]
+        line = stream[y * (rowb + 1) + 1:(y + 1) * (rowb + 1)]
+        for i in range(rowb):
+            a = int(out[y, i - bpp]) if i >= bpp else 0
+            b = int(out[y - 1, i]) if y > 0 else 0
+            c = int(out[y - 1, i - bpp]) if (y > 0 and i >= bpp) else 0
+            if ft == 0:
+                pr = 0
+            elif ft == 1:
+                pr = a
+            elif ft == 2:
+                pr = b
+            elif ft == 3:
+                pr = (a + b) >> 1
+            else:
+                pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out[y, i] = (int(line[i]) + pr) & 0xFF
+    return out
+
+
+@pytest.mark.parametrize("ct", [6, 3, 2])
+def test_defilter_kernel_group_and_band_edges(emu, ct):
+    """Widths around the 4-pixel group (partial last group, rows shorter than a group) and
+    heights around the 64-row band, filter type chosen per row at random.  Colour type 2 runs
+    the spec-conforming expansion here (replay_p3 = 0; the reference's own output for RGB is
+    test_p3_rgb_replay_kernel_matches_reference_digest)."""
+    rng = np.random.default_rng(100 + ct)
+    bpp = {6: 4, 3: 1, 2: 3}[ct]
+    pal = rng.integers(0, 256, 768, dtype=np.uint8) if ct == 3 else None
+    for w, h in [(1, 1), (2, 3), (3, 65), (4, 64), (5, 2), (7, 130), (8, 63), (63, 5), (65, 66), (130, 9)]:
+        stream = rng.integers(0, 256, h * (w * bpp + 1), dtype=np.uint8)
+        stream[:: w * bpp + 1] = rng.integers(0, 5, h)
+        want = _spec_defilter(stream, w, h, bpp).reshape(h, w, bpp)
+        rgba = _emu_defilter(emu, stream.tobytes(), w, h, ct, pal).reshape(h, w, 4)
+        if ct == 6:
+            exp = want
+        elif ct == 2:
+            exp = np.concatenate([want, np.full((h, w, 1), 255, np.uint8)], axis=2)
+        else:
+            idx = want[:, :, 0].astype(np.int64)
+            exp = np.stack([pal[idx], pal[256 + idx], pal[512 + idx], np.full((h, w), 255, np.uint8)], axis=2)
+        assert np.array_equal(rgba, exp), (ct, w, h)
+
+
 def test_p3_rgb_replay_kernel_matches_reference_digest(emu):
     """colour type 2 through debig_png_p3_kernel on the emulator: a small synthetic RGB image
     against the oracle (pinned to the reference on this behaviour by backgrounddetailed1.png)."""
