@@ -65,6 +65,48 @@ def test_multi_wavefront_kernel_crosses_windows_and_tiles(emu):
     assert r.n_windows >= 2
 
 
+def _tiny_block_streams(seed, count, max_len):
+    """Streams whose encoder flushed every few bytes (what PNG writers that flush per row
+    produce, e.g. extraturns.png: 801 blocks for 640 KB): hundreds of blocks of a few bytes,
+    fixed and dynamic codes, empty stored blocks in between; a third damaged."""
+    rng = random.Random(seed)
+    raws, caps = [], []
+    for it in range(count):
+        data = bytes(rng.choice(b"abcdefgh \n") for _ in range(rng.randint(20, max_len)))
+        strat = rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY])
+        c = zlib.compressobj(rng.choice([1, 6, 9]), zlib.DEFLATED, -15, 9, strat)
+        raw, i, maxchunk = b"", 0, rng.choice([3, 20, 60, 200])
+        while i < len(data):
+            n = rng.randint(1, maxchunk)
+            raw += c.compress(data[i:i + n])
+            i += n
+            raw += c.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_BLOCK]))
+        raw = bytearray(raw + c.flush())
+        mode = it % 3
+        if mode == 1:
+            raw = raw[: rng.randint(5, len(raw))]
+        elif mode == 2:
+            raw[rng.randrange(len(raw))] ^= 1 << rng.randrange(8)
+        raws.append(bytes(raw))
+        caps.append(max(len(data) * 3 + 64, len(raw)))
+    return raws, caps
+
+
+@pytest.mark.parametrize("nw", [1, 4])
+def test_streams_of_tiny_blocks_take_the_probe_path(emu, oracle, nw):
+    raws, caps = _tiny_block_streams(31 + nw, 24 if nw == 1 else 12, 2500)
+    outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, in_misalign=5, out_misalign=11)
+    probed = 0
+    for raw, cap, (good, final, out, r), (_, oo) in zip(raws, caps, outs, offs):
+        eg, ef, eo, st = oracle.inflate(raw, cap, want_stats=True)
+        assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
+        if st.ub_flags & (0x10 | 0x02):
+            continue
+        assert (good, final, out) == (eg, ef, eo)
+        probed += r.n_windows > 8 and r.n_rounds < 2 * r.n_windows  # one probe instead of >= 2 rounds
+    assert probed >= 4
+
+
 def test_mixed_width_launches_partition_the_batch(emu, oracle):
     """debig_hip_inflate_batch_ex's mixed mode: the 4-wavefront kernel takes the large class
     (>= 256 KiB input or >= 1 MiB recipient), the 1-wavefront kernel the rest; together they

@@ -175,6 +175,34 @@ def test_roundtrip_full_size_property(gpu_device):
         assert np.array_equal(host[off:off + 65536], plain), i
 
 
+def test_streams_of_tiny_blocks(oracle, gpu_device):
+    """Encoders that flush every few bytes (PNG writers flushing per row): hundreds of blocks of
+    a few bytes each, empty stored blocks in between, clean / truncated / bit-flipped.  These
+    run the kernels' short-block probe instead of the speculative rounds."""
+    rng = random.Random(77)
+    raws, caps = [], []
+    for it in range(300):
+        data = _payload(rng, rng.randint(20, 20000), rng.choice([1, 3, 4]))
+        strat = rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE])
+        c = zlib.compressobj(rng.choice([0, 1, 6, 9]), zlib.DEFLATED, -15, 9, strat)
+        raw, i, maxchunk = b"", 0, rng.choice([3, 20, 60, 200, 1000])
+        while i < len(data):
+            n = rng.randint(1, maxchunk)
+            raw += c.compress(data[i:i + n])
+            i += n
+            raw += c.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_BLOCK]))
+        raw = bytearray(raw + c.flush())
+        mode = it % 3
+        if mode == 1:
+            raw = raw[: rng.randint(5, len(raw))]
+        elif mode == 2:
+            for _ in range(rng.randint(1, 3)):
+                raw[rng.randrange(len(raw))] ^= 1 << rng.randrange(8)
+        raws.append(bytes(raw))
+        caps.append(max(len(data) * 3 + 64, len(raw)))
+    _check(oracle, gpu_device, raws, caps, in_skew=3, out_skew=9)
+
+
 def test_large_streams_every_width(gpu_device):
     """Few large streams (the decode_png config 4 regime): 4 MiB each, text-like fixed and
     dynamic Huffman and Paeth-filtered image rows; every kernel width must return the
