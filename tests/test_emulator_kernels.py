@@ -94,7 +94,7 @@ def _tiny_block_streams(seed, count, max_len):
 
 @pytest.mark.parametrize("nw", [1, 4])
 def test_streams_of_tiny_blocks_take_the_probe_path(emu, oracle, nw):
-    raws, caps = _tiny_block_streams(31 + nw, 24 if nw == 1 else 12, 2500)
+    raws, caps = _tiny_block_streams(31 + nw, 12 if nw == 1 else 6, 1500)
     outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, in_misalign=5, out_misalign=11)
     probed = 0
     for raw, cap, (good, final, out, r), (_, oo) in zip(raws, caps, outs, offs):
@@ -104,7 +104,7 @@ def test_streams_of_tiny_blocks_take_the_probe_path(emu, oracle, nw):
             continue
         assert (good, final, out) == (eg, ef, eo)
         probed += r.n_windows > 8 and r.n_rounds < 2 * r.n_windows  # one probe instead of >= 2 rounds
-    assert probed >= 4
+    assert probed >= 2
 
 
 def test_mixed_width_launches_partition_the_batch(emu, oracle):
