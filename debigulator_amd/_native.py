@@ -13,13 +13,14 @@ LIB_PATH = os.path.join(HERE, "lib", "libdebigulator_hip.so")
 class DebigStream(C.Structure):
     _fields_ = [("in_off", C.c_uint64), ("in_len", C.c_uint64), ("out_off", C.c_uint64),
                 ("out_cap", C.c_uint64), ("p2_s0", C.c_int64), ("p2_est", C.c_uint64),
-                ("p2_on", C.c_uint32), ("reserved", C.c_uint32)]
+                ("p2_on", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class DebigResult(C.Structure):
     _fields_ = [("final_size", C.c_uint64), ("good", C.c_uint32), ("status", C.c_uint32),
                 ("final_set", C.c_uint32), ("n_blocks", C.c_uint32), ("n_windows", C.c_uint32),
-                ("n_rounds", C.c_uint32), ("prof", C.c_uint32 * 8)]
+                ("n_rounds", C.c_uint32), ("prof", C.c_uint32 * 8),
+                ("in_end_bits", C.c_uint64)]
 
 
 class DebigPngImage(C.Structure):

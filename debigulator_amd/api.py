@@ -183,3 +183,28 @@ def decode_gz_batch(datas, out_caps, verify_trailer=True):
     rc = L.debig_decode_gz_batch_ex(in_ptrs, in_sizes, out_ptrs, caps, sizes, goods, tok if verify_trailer else None, n)
     N.check(rc, "debig_decode_gz_batch_ex")
     return [(goods[i], outs[i][: sizes[i]].tobytes(), tok[i]) for i in range(n)]
+
+
+GZ_STATUS = {0: "ok", 1: "header", 2: "truncated", 3: "inflate", 4: "output_full", 5: "crc", 6: "isize", 7: "trailing"}
+
+
+def gunzip_batch(datas, out_caps):
+    """RFC 1952-complete gunzip of n files (include/decode_gz.h: debig_gunzip_batch): every
+    member, every optional header field, CRC-32/ISIZE verified on the GPU.
+    -> [(status, bytes, n_members)], status as in GZ_STATUS."""
+    L = _lib()
+    L.debig_gunzip_batch.restype = C.c_int
+    L.debig_gunzip_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint32]
+    n = len(datas)
+    ins = [_u8(d) for d in datas]
+    outs = [np.zeros(max(c, 1), dtype=np.uint8) for c in out_caps]
+    in_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in ins])
+    in_sizes = (C.c_uint64 * n)(*[len(d) for d in datas])
+    out_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in outs])
+    caps = (C.c_uint64 * n)(*out_caps)
+    sizes = (C.c_uint64 * n)()
+    status = (C.c_uint32 * n)()
+    members = (C.c_uint32 * n)()
+    rc = L.debig_gunzip_batch(in_ptrs, in_sizes, out_ptrs, caps, sizes, status, members, n)
+    N.check(rc, "debig_gunzip_batch")
+    return [(status[i], outs[i][: sizes[i]].tobytes(), members[i]) for i in range(n)]

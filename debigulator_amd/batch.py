@@ -13,9 +13,10 @@ import numpy as np
 from . import _native as N
 
 STREAM_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u8"), ("out_off", "<u8"), ("out_cap", "<u8"),
-                         ("p2_s0", "<i8"), ("p2_est", "<u8"), ("p2_on", "<u4"), ("reserved", "<u4")])
+                         ("p2_s0", "<i8"), ("p2_est", "<u8"), ("p2_on", "<u4"), ("flags", "<u4")])
 RESULT_DTYPE = np.dtype([("final_size", "<u8"), ("good", "<u4"), ("status", "<u4"), ("final_set", "<u4"),
-                         ("n_blocks", "<u4"), ("n_windows", "<u4"), ("n_rounds", "<u4"), ("prof", "<u4", (8,))])
+                         ("n_blocks", "<u4"), ("n_windows", "<u4"), ("n_rounds", "<u4"), ("prof", "<u4", (8,)),
+                         ("in_end_bits", "<u8")])
 assert STREAM_DTYPE.itemsize == C.sizeof(N.DebigStream)
 assert RESULT_DTYPE.itemsize == C.sizeof(N.DebigResult)
 
@@ -26,7 +27,7 @@ def _align(x, a):
     return (x + a - 1) // a * a
 
 
-def pack_streams(raws, caps, in_align=16, out_align=16, in_skew=0, out_skew=0, p2=None):
+def pack_streams(raws, caps, in_align=16, out_align=16, in_skew=0, out_skew=0, p2=None, flags=0):
     """Lay n compressed streams and their recipients out in two arenas (host side).
 
     Returns (in_arena uint8[], streams structured[], out_bytes)."""
@@ -41,6 +42,7 @@ def pack_streams(raws, caps, in_align=16, out_align=16, in_skew=0, out_skew=0, p
         streams[i]["in_len"] = len(raws[i])
         streams[i]["out_off"] = out_off
         streams[i]["out_cap"] = caps[i]
+        streams[i]["flags"] = flags
         if p2 is not None and p2[i] is not None:
             streams[i]["p2_on"] = 1
             streams[i]["p2_s0"] = p2[i][0]

@@ -117,6 +117,254 @@ done:
     return rc;
 }
 
+/* ---------------------------------------------------------------------------------------
+ * debig_gunzip_batch: RFC 1952 complete (include/decode_gz.h).  Not a reference function.
+ * ------------------------------------------------------------------------------------- */
+static uint32_t le16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+static uint32_t le32(const uint8_t *p) { return le16(p) | (le16(p + 2) << 16); }
+
+/* One member header at p (avail bytes left in the file).  Returns DEBIG_GZ_OK and the header
+ * length; *bsize = total member size from a BGZF "BC" subfield, 0 when there is none. */
+static uint32_t gz_member_header(const uint8_t *p, uint64_t avail, uint64_t *hdr_len, uint64_t *bsize)
+{
+    *bsize = 0;
+    if (avail < 10) return avail >= 2 && (p[0] != 31 || p[1] != 139) ? DEBIG_GZ_E_HEADER : DEBIG_GZ_E_TRUNCATED;
+    if (p[0] != 31 || p[1] != 139 || p[2] != 8 || (p[3] & 0xE0u)) return DEBIG_GZ_E_HEADER;
+    const uint32_t flg = p[3];
+    uint64_t o = 10;
+    if (flg & 4u) { /* FEXTRA */
+        if (o + 2 > avail) return DEBIG_GZ_E_TRUNCATED;
+        uint64_t xlen = le16(p + o);
+        o += 2;
+        if (o + xlen > avail) return DEBIG_GZ_E_TRUNCATED;
+        for (uint64_t q = o; q + 4 <= o + xlen;) { /* subfields: SI1 SI2 LEN data */
+            uint64_t sl = le16(p + q + 2);
+            if (q + 4 + sl > o + xlen) break;
+            if (p[q] == 'B' && p[q + 1] == 'C' && sl == 2) *bsize = (uint64_t)le16(p + q + 4) + 1u;
+            q += 4 + sl;
+        }
+        o += xlen;
+    }
+    for (uint32_t bit = 8u; bit <= 16u; bit <<= 1) /* FNAME, FCOMMENT: zero-terminated */
+        if (flg & bit) {
+            while (o < avail && p[o] != 0) o++;
+            if (o >= avail) return DEBIG_GZ_E_TRUNCATED;
+            o++;
+        }
+    if (flg & 2u) { /* FHCRC */
+        if (o + 2 > avail) return DEBIG_GZ_E_TRUNCATED;
+        o += 2;
+    }
+    *hdr_len = o;
+    return DEBIG_GZ_OK;
+}
+
+typedef struct gz_item { /* one member in flight */
+    uint32_t file;
+    uint64_t payload;    /* file offset of its DEFLATE data            */
+    uint64_t known_end;  /* file offset just past its trailer, or 0    */
+    uint64_t out_rel;    /* where its output starts in the file's output */
+} gz_item;
+
+typedef struct gz_file {
+    uint64_t pos;      /* file offset of the next member header            */
+    uint64_t used;     /* output bytes of the members verified so far      */
+    uint64_t dev_in, dev_out;
+    uint32_t status, members;
+    uint32_t active;   /* has a member to decode in the next pass          */
+    uint32_t failed;   /* an error ended this file                         */
+} gz_file;
+
+static int gz_all_zero(const uint8_t *p, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; i++)
+        if (p[i]) return 0;
+    return 1;
+}
+
+DEBIG_API int debig_gunzip_batch(const uint8_t *const *inputs, const uint64_t *input_sizes,
+                                 uint8_t *const *outs, const uint64_t *out_caps, uint64_t *out_sizes,
+                                 uint32_t *status, uint32_t *n_members, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        out_sizes[i] = 0;
+        status[i] = DEBIG_GZ_E_HEADER;
+        if (n_members) n_members[i] = 0;
+    }
+    if (n == 0) return 0;
+    debig_ctx *c = debig_ctx_get(0);
+    if (!c) return 1;
+    gz_file *F = (gz_file *)calloc(n, sizeof(gz_file));
+    gz_item *items = NULL;
+    debig_stream *desc = NULL;
+    debig_result *res = NULL;
+    debig_span *spans = NULL;
+    uint32_t *crcs = NULL;
+    uint64_t cap_items = 0;
+    int rc = 2;
+    if (!F) goto done;
+    /* ---- whole files and the output regions go to / live in HBM once */
+    uint64_t in_total = 0, out_total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        F[i].dev_in = in_total;
+        F[i].dev_out = out_total;
+        F[i].active = inputs[i] != NULL && outs[i] != NULL;
+        F[i].status = F[i].active ? DEBIG_GZ_OK : DEBIG_GZ_E_HEADER;
+        F[i].failed = !F[i].active;
+        if (!F[i].active) continue;
+        in_total += debig_align16(input_sizes[i]) + 16;
+        out_total += debig_align16(out_caps[i]) + 16;
+    }
+    if ((rc = debig_devbuf_reserve(&c->files, in_total + 64)) || (rc = debig_devbuf_reserve(&c->out, out_total + 64)))
+        goto done;
+    for (uint32_t i = 0; i < n && !rc; i++)
+        if (F[i].active && input_sizes[i])
+            rc = debig_hip_memcpy_h2d((uint8_t *)c->files.ptr + F[i].dev_in, inputs[i], input_sizes[i], NULL);
+    if (rc) goto done;
+
+    for (;;) {
+        /* ---- this pass: the next member of every active file; every member of a BGZF file */
+        uint64_t n_items = 0;
+        for (int fill = 0; fill < 2; fill++) { /* 0: count, 1: fill */
+            n_items = 0;
+            for (uint32_t i = 0; i < n; i++) {
+                if (!F[i].active) continue;
+                uint64_t pos = F[i].pos, used = F[i].used;
+                uint32_t queued = 0; /* members of this file in this pass */
+                for (;;) {
+                    uint64_t hl = 0, bs = 0;
+                    uint32_t st = gz_member_header(inputs[i] + pos, input_sizes[i] - pos, &hl, &bs);
+                    if (st != DEBIG_GZ_OK) {
+                        /* behind queued members the next pass meets this header again, first */
+                        if (fill && !queued) { F[i].status = st; F[i].failed = 1; F[i].active = 0; }
+                        break;
+                    }
+                    /* a BGZF member: its end and (from ISIZE) its output size are known now */
+                    int bg = bs >= hl + 8 && pos + bs <= input_sizes[i];
+                    if (fill) {
+                        items[n_items].file = i;
+                        items[n_items].payload = pos + hl;
+                        items[n_items].known_end = bg ? pos + bs : 0;
+                        items[n_items].out_rel = used;
+                    }
+                    n_items++;
+                    queued++;
+                    if (!bg) break;
+                    used += le32(inputs[i] + pos + bs - 4);
+                    pos += bs;
+                    if (input_sizes[i] - pos < 10 || inputs[i][pos] != 31 || inputs[i][pos + 1] != 139) break;
+                }
+            }
+            if (!fill) {
+                if (n_items == 0) break;
+                if (n_items > cap_items) {
+                    free(items); free(desc); free(res); free(spans); free(crcs);
+                    cap_items = n_items + n_items / 2 + 16;
+                    items = (gz_item *)calloc(cap_items, sizeof(gz_item));
+                    desc = (debig_stream *)calloc(cap_items, sizeof(debig_stream));
+                    res = (debig_result *)calloc(cap_items, sizeof(debig_result));
+                    spans = (debig_span *)calloc(cap_items, sizeof(debig_span));
+                    crcs = (uint32_t *)calloc(cap_items, sizeof(uint32_t));
+                    if (!items || !desc || !res || !spans || !crcs) { rc = 2; goto done; }
+                }
+            }
+        }
+        if (n_items == 0) break;
+        if (n_items > 0xffffffffull) { rc = 2; goto done; }
+        const uint32_t m = (uint32_t)n_items;
+        memset(desc, 0, (size_t)m * sizeof(debig_stream));
+        for (uint32_t k = 0; k < m; k++) {
+            const gz_item *it = &items[k];
+            const uint32_t i = it->file;
+            desc[k].in_off = F[i].dev_in + it->payload;
+            /* the trailer (and whatever follows) stays part of the input span: the end-of-input
+             * rule of the reference's inflate (Q2) never sees the stream's last byte */
+            desc[k].in_len = (it->known_end ? it->known_end : input_sizes[i]) - it->payload;
+            desc[k].out_off = F[i].dev_out + it->out_rel;
+            desc[k].out_cap = it->out_rel <= out_caps[i] ? out_caps[i] - it->out_rel : 0;
+            desc[k].flags = DEBIG_STREAM_NO_REF_GATES;
+        }
+        if ((rc = debig_devbuf_reserve(&c->desc, (uint64_t)m * sizeof(debig_stream))) ||
+            (rc = debig_devbuf_reserve(&c->res, (uint64_t)m * sizeof(debig_result))) ||
+            (rc = debig_devbuf_reserve(&c->spans, (uint64_t)m * sizeof(debig_span))) ||
+            (rc = debig_devbuf_reserve(&c->crcs, (uint64_t)m * sizeof(uint32_t))) ||
+            (rc = debig_hip_memcpy_h2d(c->desc.ptr, desc, (uint64_t)m * sizeof(debig_stream), NULL)) ||
+            (rc = debig_hip_inflate_batch_ex(c->files.ptr, c->out.ptr, (const debig_stream *)c->desc.ptr,
+                                             (debig_result *)c->res.ptr, m, debig_pick_waves(desc, m), NULL)) ||
+            (rc = debig_hip_memcpy_d2h(res, c->res.ptr, (uint64_t)m * sizeof(debig_result), NULL)) ||
+            (rc = debig_hip_stream_sync(NULL)))
+            goto done;
+        for (uint32_t k = 0; k < m; k++) {
+            spans[k].off = desc[k].out_off;
+            spans[k].len = res[k].good ? res[k].final_size : 0;
+        }
+        if ((rc = debig_hip_memcpy_h2d(c->spans.ptr, spans, (uint64_t)m * sizeof(debig_span), NULL)) ||
+            (rc = debig_hip_checksum_batch(c->out.ptr, (const debig_span *)c->spans.ptr, (uint32_t *)c->crcs.ptr, m, 0, NULL)) ||
+            (rc = debig_hip_memcpy_d2h(crcs, c->crcs.ptr, (uint64_t)m * sizeof(uint32_t), NULL)) ||
+            (rc = debig_hip_stream_sync(NULL)))
+            goto done;
+        /* ---- verdicts, in member order per file */
+        for (uint32_t k = 0; k < m; k++) {
+            const gz_item *it = &items[k];
+            const uint32_t i = it->file;
+            gz_file *f = &F[i];
+            if (f->failed) continue; /* an earlier member of this file failed */
+            if (!res[k].good) {
+                f->status = res[k].status == DEBIG_E_OUTPUT_FULL ? DEBIG_GZ_E_OUTPUT_FULL : DEBIG_GZ_E_INFLATE;
+                f->failed = 1;
+                continue;
+            }
+            const uint64_t end = it->payload + (res[k].in_end_bits + 7u) / 8u; /* the trailer starts here */
+            if (end + 8 > input_sizes[i]) { f->status = DEBIG_GZ_E_TRUNCATED; f->failed = 1; continue; }
+            if (it->known_end && end + 8 != it->known_end) { /* the BC size disagrees with the stream */
+                f->status = DEBIG_GZ_E_INFLATE;
+                f->failed = 1;
+                continue;
+            }
+            if (it->out_rel != f->used) { /* the ISIZE of an earlier BGZF member was wrong */
+                f->status = DEBIG_GZ_E_ISIZE;
+                f->failed = 1;
+                continue;
+            }
+            const uint8_t *t = inputs[i] + end;
+            f->used += res[k].final_size;
+            f->members++;
+            f->pos = end + 8;
+            if (le32(t) != crcs[k]) { f->status = DEBIG_GZ_E_CRC; f->failed = 1; continue; }
+            if (le32(t + 4) != (uint32_t)res[k].final_size) { f->status = DEBIG_GZ_E_ISIZE; f->failed = 1; continue; }
+        }
+        /* ---- which files go on */
+        for (uint32_t i = 0; i < n; i++) {
+            gz_file *f = &F[i];
+            if (!f->active) continue;
+            if (f->failed) { f->active = 0; continue; }
+            const uint64_t left = input_sizes[i] - f->pos;
+            if (left == 0 || gz_all_zero(inputs[i] + f->pos, left)) { f->active = 0; continue; }
+            if (left < 10 || inputs[i][f->pos] != 31 || inputs[i][f->pos + 1] != 139) {
+                f->status = DEBIG_GZ_E_TRAILING;
+                f->active = 0;
+            }
+        }
+    }
+    /* ---- results back to the host */
+    rc = 0;
+    for (uint32_t i = 0; i < n && !rc; i++) {
+        status[i] = F[i].status;
+        if (n_members) n_members[i] = F[i].members;
+        out_sizes[i] = F[i].used;
+        if (F[i].used && outs[i]) rc = debig_hip_memcpy_d2h(outs[i], (uint8_t *)c->out.ptr + F[i].dev_out, F[i].used, NULL);
+    }
+    if (!rc) rc = debig_hip_stream_sync(NULL);
+done:
+    free(F);
+    free(items);
+    free(desc);
+    free(res);
+    free(spans);
+    free(crcs);
+    return rc;
+}
+
 DEBIG_API DecodedData *decode_gz(uint8_t *compressed_bytes, uint32_t compressed_bytes_size)
 {
     if (g_malloc == NULL) return NULL; /* src/decode_gz.c:105-113 */

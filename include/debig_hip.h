@@ -35,8 +35,14 @@ typedef struct debig_stream {
     int64_t p2_s0;
     uint64_t p2_est;
     uint32_t p2_on;
-    uint32_t reserved;
+    uint32_t flags;   /* DEBIG_STREAM_* (0 = exactly the reference's inflate())         */
 } debig_stream;
+
+/* debig_stream.flags.  NO_REF_GATES: skip the reference's argument gates
+ * (recipient_size < compressed_input_size, compressed_input_size < 5; quirk Q1) -- for
+ * callers outside the reference's API whose input span is not "one stream", e.g. a gzip
+ * member followed by further members (debig_gunzip_batch). */
+#define DEBIG_STREAM_NO_REF_GATES 1u
 
 /* status codes in debig_result.status (0 = success) */
 enum {
@@ -62,8 +68,12 @@ typedef struct debig_result {
     uint32_t n_rounds;   /* speculative rounds summed over windows                     */
     /* shader-clock cycles per phase, only filled by -DDEBIG_PROFILE builds (else 0):
      * 0 stage input, 1 pass-1 scan rounds, 2 pass-2 decode, 3 LZ77 resolve, 4 flush,
-     * 5 headers + tables, 6 whole stream, 7 reserved */
+     * 5 headers + tables, 6 whole stream, 7 far-match copy */
     uint32_t prof[8];
+    /* bit position (relative to the stream's first byte) where decoding stopped: just past the
+     * end-of-block code of the final block on success.  ceil(in_end_bits / 8) is where a
+     * container's trailer starts (gzip CRC-32/ISIZE, zlib Adler-32). */
+    uint64_t in_end_bits;
 } debig_result;
 
 /* Inflate n independent raw DEFLATE streams.  All pointers are DEVICE pointers

@@ -39,6 +39,36 @@ int debig_decode_gz_batch_ex(const uint8_t *const *inputs, const uint32_t *input
                              uint8_t *const *outs, const uint64_t *out_caps, uint64_t *out_sizes,
                              uint32_t *goods, uint32_t *trailer_ok, uint32_t n);
 
+/* ---- beyond the reference: complete RFC 1952 handling -----------------
+ * decode_gz() above keeps the reference's header rules (only FNAME is skipped, first member
+ * only, trailer ignored).  debig_gunzip_batch is what a real-world .gz corpus needs:
+ *   - FEXTRA, FNAME, FCOMMENT and FHCRC are all skipped correctly; reserved FLG bits reject;
+ *   - every member of a multi-member file is decoded and the outputs are concatenated;
+ *   - the CRC-32 and ISIZE of every member are verified (CRC computed on the GPU);
+ *   - files whose members carry their size in a "BC" extra subfield (BGZF) are split on the
+ *     host, so all their members are inflated by ONE launch; other multi-member files take
+ *     one launch per member rank (member k of every file together), because a member's end
+ *     is only known once it has been inflated;
+ *   - inflate runs without the reference's size gates and without its end-of-input quirk
+ *     (the trailer bytes follow the stream), i.e. plain RFC 1951 output.
+ * Zero bytes after the last member are accepted (tape padding); anything else that is not
+ * a gzip header ends the file with DEBIG_GZ_E_TRAILING.
+ * status[i]: DEBIG_GZ_*; out_sizes[i]: bytes produced (also on error: what was decoded before
+ * it); n_members[i]: members decoded (may be NULL).  Returns 0 or a device error code. */
+enum {
+    DEBIG_GZ_OK = 0,
+    DEBIG_GZ_E_HEADER = 1,      /* not a gzip header / CM != 8 / reserved flag bits       */
+    DEBIG_GZ_E_TRUNCATED = 2,   /* header, stream or trailer runs past the end of the file */
+    DEBIG_GZ_E_INFLATE = 3,     /* the DEFLATE stream is damaged                           */
+    DEBIG_GZ_E_OUTPUT_FULL = 4, /* out_caps[i] is too small                                */
+    DEBIG_GZ_E_CRC = 5,         /* CRC-32 of a member does not match its trailer           */
+    DEBIG_GZ_E_ISIZE = 6,       /* ISIZE of a member does not match                        */
+    DEBIG_GZ_E_TRAILING = 7     /* garbage after the last member (output is complete)      */
+};
+int debig_gunzip_batch(const uint8_t *const *inputs, const uint64_t *input_sizes,
+                       uint8_t *const *outs, const uint64_t *out_caps, uint64_t *out_sizes,
+                       uint32_t *status, uint32_t *n_members, uint32_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,13 +13,14 @@ EMU_DIR = os.path.join(ROOT, "tools", "simt_emu")
 class DebigStream(C.Structure):
     _fields_ = [("in_off", C.c_uint64), ("in_len", C.c_uint64), ("out_off", C.c_uint64),
                 ("out_cap", C.c_uint64), ("p2_s0", C.c_int64), ("p2_est", C.c_uint64),
-                ("p2_on", C.c_uint32), ("reserved", C.c_uint32)]
+                ("p2_on", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class DebigResult(C.Structure):
     _fields_ = [("final_size", C.c_uint64), ("good", C.c_uint32), ("status", C.c_uint32),
                 ("final_set", C.c_uint32), ("n_blocks", C.c_uint32), ("n_windows", C.c_uint32),
-                ("n_rounds", C.c_uint32), ("prof", C.c_uint32 * 8)]
+                ("n_rounds", C.c_uint32), ("prof", C.c_uint32 * 8),
+                ("in_end_bits", C.c_uint64)]
 
 
 def load_emu(asan=False):
@@ -37,7 +38,7 @@ def load_emu(asan=False):
     return L
 
 
-def layout_batch(raws, caps, in_misalign=0, out_misalign=0, p2=None):
+def layout_batch(raws, caps, in_misalign=0, out_misalign=0, p2=None, flags=0):
     """Pack streams into arenas.  Returns (in_arena, out_arena, streams[], results[])."""
     n = len(raws)
     streams = (DebigStream * n)()
@@ -50,6 +51,7 @@ def layout_batch(raws, caps, in_misalign=0, out_misalign=0, p2=None):
         streams[i].in_len = len(r)
         streams[i].out_off = out_off
         streams[i].out_cap = cap
+        streams[i].flags = flags
         if p2 is not None and p2[i] is not None:
             streams[i].p2_on = 1
             streams[i].p2_s0 = p2[i][0]

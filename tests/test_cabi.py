@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(native_lib):
             "inflate_destroy", "decode_png", "decode_png_init", "decode_png_deinit",
             "decode_png_get_width_height", "decode_gz", "init_decode_gz", "decode_PNG", "init_PNG_decoder",
             "get_PNG_width_height", "debig_inflate_batch", "debig_decode_png_batch",
-            "debig_decode_gz_batch"} <= declared
+            "debig_decode_gz_batch", "debig_gunzip_batch"} <= declared
     missing = [n for n in sorted(declared) if not hasattr(native_lib, n)]
     assert not missing, missing
 
@@ -53,5 +53,5 @@ def test_struct_layouts_match_header():
     from debigulator_amd.batch import RESULT_DTYPE, STREAM_DTYPE
 
     assert ctypes.sizeof(N.DebigStream) == 56 == STREAM_DTYPE.itemsize
-    assert ctypes.sizeof(N.DebigResult) == 64 == RESULT_DTYPE.itemsize
+    assert ctypes.sizeof(N.DebigResult) == 72 == RESULT_DTYPE.itemsize
     assert ctypes.sizeof(N.DebigPngImage) == 56

@@ -65,6 +65,33 @@ def test_multi_wavefront_kernel_crosses_windows_and_tiles(emu):
     assert r.n_windows >= 2
 
 
+@pytest.mark.parametrize("nw", [1, 4])
+def test_end_position_and_no_gates_flag(emu, nw):
+    """debig_result.in_end_bits (where decoding stopped) and DEBIG_STREAM_NO_REF_GATES: what a
+    container with several members needs (debig_gunzip_batch).  A raw stream followed by other
+    bytes is decoded with in_len covering all of them; the reported end is the last bit of the
+    DEFLATE data, and the reference's size gates (Q1) do not apply."""
+    rng = random.Random(12)
+    raws, plains, ends = [], [], []
+    for it in range(12):
+        data = bytes(rng.choice(b"abcdefgh \n") for _ in range(rng.randint(1, 9000)))
+        strat = rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY])
+        c = zlib.compressobj(rng.choice([0, 1, 9]), zlib.DEFLATED, -15, 9, strat)
+        raw = c.compress(data) + c.flush()
+        tail = bytes(rng.getrandbits(8) for _ in range(rng.randint(8, 40)))
+        raws.append(raw + tail)
+        plains.append(data)
+        ends.append(len(raw))
+    caps = [len(p) for p in plains]  # exact: smaller than in_len for the short ones (gate Q1 would reject)
+    outs, _, _ = eb.emu_inflate(emu, raws, caps, nw=nw, flags=1)
+    for (good, final, out, r), plain, end in zip(outs, plains, ends):
+        assert (good, final, out) == (1, len(plain), plain)
+        assert (r.in_end_bits + 7) // 8 == end
+    # without the flag the same descriptors hit the reference's gate when recipient < input
+    outs, _, _ = eb.emu_inflate(emu, raws, caps, nw=nw)
+    assert any(good == 0 and r.status == 1 for good, _, _, r in outs)
+
+
 def _tiny_block_streams(seed, count, max_len):
     """Streams whose encoder flushed every few bytes (what PNG writers that flush per row
     produce, e.g. extraturns.png: 801 blocks for 640 KB): hundreds of blocks of a few bytes,

@@ -210,3 +210,95 @@ def test_checksum_kernels_vs_zlib(gpu_device):
         got = ck.results()
         for (o, n), g in zip(spans, got):
             assert g == fn(host[o:o + n].tobytes()), (kind, o, n)
+
+
+# ---------------------------------------------------------------------------------------------
+# debig_gunzip_batch (include/decode_gz.h): beyond the reference -- complete RFC 1952 headers,
+# multi-member files, CRC-32/ISIZE verified on the GPU.  Ground truth: Python's zlib/gzip.
+def _gz_member(data, level=6, name=None, comment=None, extra=None, hcrc=False, text=False):
+    import struct
+    import zlib
+
+    flg = (1 if text else 0) | (2 if hcrc else 0) | (4 if extra is not None else 0) | (8 if name else 0) | \
+        (16 if comment else 0)
+    h = bytes([31, 139, 8, flg, 0, 0, 0, 0, 0, 255])
+    if extra is not None:
+        h += struct.pack("<H", len(extra)) + extra
+    if name:
+        h += name + b"\0"
+    if comment:
+        h += comment + b"\0"
+    if hcrc:
+        h += struct.pack("<H", zlib.crc32(h) & 0xFFFF)
+    c = zlib.compressobj(level, zlib.DEFLATED, -15)
+    body = c.compress(data) + c.flush()
+    return h + body + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
+
+
+def _bgzf_member(data, level=6):
+    import struct
+
+    plain = _gz_member(data, level, extra=b"BC\x02\x00\x00\x00")
+    m = bytearray(plain)
+    struct.pack_into("<H", m, 16, len(m) - 1)  # BSIZE = total member size - 1 (after SI1 SI2 LEN at 12..15)
+    return bytes(m)
+
+
+def test_gunzip_batch_headers_members_and_trailers(api):
+    import gzip
+    import random
+
+    rng = random.Random(5)
+
+    def blob(n):
+        return bytes(rng.choice(b"abcdefgh \n") for _ in range(n))
+
+    files, want = [], []
+    # 0: python's own gzip writer (FNAME set via GzipFile default, mtime) -- the plain case
+    d0 = blob(70000)
+    files.append(gzip.compress(d0, 6)); want.append((0, d0, 1))
+    # 1: every optional header field at once
+    d1 = blob(5000)
+    files.append(_gz_member(d1, 9, name=b"a name.txt", comment=b"a comment", extra=b"XY\x03\x00abc", hcrc=True, text=True))
+    want.append((0, d1, 1))
+    # 2: five members, different levels (incl. stored), different optional fields, an empty member
+    parts = [blob(30000), blob(1), b"", blob(100000), blob(257)]
+    files.append(_gz_member(parts[0], 1) + _gz_member(parts[1], 0, name=b"x") + _gz_member(parts[2], 6) +
+                 _gz_member(parts[3], 9, comment=b"c") + _gz_member(parts[4], 6, hcrc=True))
+    want.append((0, b"".join(parts), 5))
+    # 3: BGZF-style: 40 members with their size in a BC subfield + the empty EOF member
+    chunks = [blob(rng.randint(1, 20000)) for _ in range(40)]
+    files.append(b"".join(_bgzf_member(c) for c in chunks) + _bgzf_member(b""))
+    want.append((0, b"".join(chunks), 41))
+    # 4: zero padding after the last member is accepted; 5: other bytes are reported
+    d4 = blob(3000)
+    files.append(_gz_member(d4) + b"\0" * 1000); want.append((0, d4, 1))
+    files.append(_gz_member(d4) + b"garbage!garbage!"); want.append((7, d4, 1))
+    # 6: a damaged second member keeps the first one's output; 7: CRC mismatch; 8: ISIZE mismatch
+    m2 = bytearray(_gz_member(blob(20000)))
+    m2[len(m2) // 2] ^= 0x10
+    files.append(_gz_member(d4) + bytes(m2)); want.append((None, d4, 1))
+    bad_crc = bytearray(_gz_member(d4)); bad_crc[-8] ^= 1
+    files.append(bytes(bad_crc)); want.append((5, d4, 1))
+    bad_isz = bytearray(_gz_member(d4)); bad_isz[-1] ^= 1
+    files.append(bytes(bad_isz)); want.append((6, d4, 1))
+    # 9: truncated inside the stream; 10: not gzip; 11: reserved flag bit; 12: output too small
+    files.append(_gz_member(blob(50000))[:2000]); want.append((None, None, 0))
+    files.append(b"PK\x03\x04 not a gzip file at all"); want.append((1, b"", 0))
+    r = bytearray(_gz_member(d4)); r[3] |= 0x40
+    files.append(bytes(r)); want.append((1, b"", 0))
+    files.append(_gz_member(blob(50000))); want.append((4, None, 0))
+    caps = [len(w[1]) + 64 if w[1] is not None else 1 << 17 for w in want]
+    caps[12] = 1000
+    got = api.gunzip_batch(files, caps)
+    for i, ((st, out, members), (wst, wout, wmem)) in enumerate(zip(got, want)):
+        if wst is not None:
+            assert st == wst, (i, api.GZ_STATUS[st])
+        else:
+            assert st not in (0, 7), (i, api.GZ_STATUS[st])  # damaged: some error, whichever check trips first
+        if wout is not None:
+            assert out == wout, i
+        if wst == 0:
+            assert members == wmem, (i, members)
+    # python agrees on the multi-member file
+    assert gzip.decompress(files[2]) == want[2][1]
