@@ -7,12 +7,19 @@
  * void* (NULL = the default stream).
  *
  * What each entry point replaces in the reference (ArtOfBBQ/debigulator):
- *   debig_hip_inflate_batch     N x inflate()            src/inflate.h:51-60, src/inflate.c:786-1965
+ *   debig_hip_inflate_batch      N x inflate()           src/inflate.h:51-60, src/inflate.c:786-1965
+ *   debig_hip_inflate_batch_ex   the same, with the number of wavefronts per stream chosen
+ *                                by the caller (few large streams vs thousands of small ones)
  *   debig_hip_png_defilter_batch the de-filter + palette loops of decode_png()
  *                                                         src/decode_png.c:1381-1564
+ *   debig_hip_checksum_batch     update_crc() over PNG chunks, src/decode_png.c:313-333 (and the
+ *                                gzip CRC-32 / zlib Adler-32 trailers the reference never checks)
+ *   debig_hip_gather             the IDAT concatenation decode_png does in the caller's buffer,
+ *                                src/decode_png.c:1285-1291, as a device-to-device copy list
  * The single-call drop-in API (inflate / decode_png / decode_gz with the
  * reference's own prototypes) is in inflate.h, decode_png.h, decode_gz.h next to
- * this file and is implemented on top of these batch calls.
+ * this file and is implemented on top of these batch calls; decode_gz.h also has
+ * debig_gunzip_batch, an RFC 1952-complete gunzip that goes beyond the reference.
  */
 #ifndef DEBIG_HIP_H
 #define DEBIG_HIP_H
