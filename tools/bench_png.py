@@ -30,8 +30,10 @@ else:
     side = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
     count = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     t0 = time.time()
-    distinct = [workload.make_png(9000 + s, side, side, ct=6, ftype=4, noise=24, enc="dynamic", idat_chunk=65536)[0]
-                for s in range(min(count, 2))]
+    made = [workload.make_png(9000 + s, side, side, ct=6, ftype=4, noise=24, enc="dynamic", idat_chunk=65536)
+            for s in range(min(count, 2))]
+    distinct = [m[0] for m in made]
+    pixels = [m[1] for m in made]  # what must come out: [h, w*4] bytes
     pngs = [distinct[i % len(distinct)] for i in range(count)]
     label = f"cfg4 shape: {count} x {side}x{side} RGBA all-Paeth PNGs (generated in {time.time()-t0:.0f} s)"
 b = DevicePngBatch(pngs)
@@ -40,8 +42,14 @@ t_inf = timeit(b.launch_inflate_only)
 t_def = timeit(b.launch_defilter_only)
 res, ires = b.results()
 assert (res["good"] == 1).all() and (ires["good"] == 1).all()
+checked = ""
+if which != "cfg3":  # the generator's own pixels are the expected output (round-trip property)
+    b.launch()
+    for i in sorted(set([0, 1 % count, count - 1])):
+        assert np.array_equal(b.rgba(i), np.asarray(pixels[i % len(pixels)]).reshape(-1)), f"image {i} differs"
+    checked = "; images 0, 1 and last byte-exact vs the generator's pixels"
 P, Cb, Sb = b.rgba_bytes, b.c_bytes, b.s_bytes
-print(label)
+print(label + checked)
 print(f"  inflate+defilter {t_all:9.3f} ms  {P/t_all/1e6:8.1f} GB/s of RGBA   (C={Cb/1e6:.1f} MB, S={Sb/1e6:.1f} MB, P={P/1e6:.1f} MB)")
 print(f"  inflate only     {t_inf:9.3f} ms  {Sb/t_inf/1e6:8.1f} GB/s of scanline stream")
 print(f"  de-filter only   {t_def:9.3f} ms  {(Sb+P)/t_def/1e6:8.1f} GB/s (S+P)")
