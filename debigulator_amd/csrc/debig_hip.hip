@@ -78,7 +78,7 @@ int debig_hip_gather(const void *d_src_arena, void *d_dst_arena, const debig_cop
 // Wavefronts per stream when the caller leaves the choice to the library.  The chip is full
 // at about 2048 resident decode wavefronts (256 CUs x 4 SIMDs x 2); with fewer streams than
 // that, several wavefronts share one stream (debig_inflate_mw_kernel).  Measured crossovers
-// (profiles/r01_mw_sweep.txt): n <= 512 -> 4, n <= 1024 -> 2, else 1.  The mixed modes are
+// (profiles/r01_mw_sweep.txt): n <= 256 -> 8, n <= 512 -> 4, n <= 1024 -> 2, else 1.  The mixed modes are
 // never picked here: they only pay when FEW streams of a big batch are large, and stream
 // sizes live in device memory -- callers that know them ask for a mixed mode themselves
 // (csrc/host/debig_ctx.c: debig_pick_waves).
@@ -93,6 +93,7 @@ static uint32_t auto_waves_per_stream(uint32_t n)
         env_read = 1;
     }
     if (env_val) return env_val;
+    if (n <= 256u) return 8u;
     if (n <= 512u) return 4u;
     if (n <= 1024u) return 2u;
     return 1u;
@@ -108,8 +109,11 @@ static int launch_inflate(uint32_t width, uint32_t cls, hipStream_t s, const voi
     else if (width == 2)
         hipLaunchKernelGGL(debig_inflate_mw_kernel<2>, dim3(grid), dim3(128), 0, s, (const uint8_t *)d_in,
                            (uint8_t *)d_out, d_streams, d_results, n, ft, cls);
-    else
+    else if (width == 4)
         hipLaunchKernelGGL(debig_inflate_mw_kernel<4>, dim3(grid), dim3(256), 0, s, (const uint8_t *)d_in,
+                           (uint8_t *)d_out, d_streams, d_results, n, ft, cls);
+    else
+        hipLaunchKernelGGL(debig_inflate_mw_kernel<8>, dim3(grid), dim3(512), 0, s, (const uint8_t *)d_in,
                            (uint8_t *)d_out, d_streams, d_results, n, ft, cls);
     return (int)hipGetLastError();
 }
@@ -141,7 +145,7 @@ int debig_hip_inflate_batch_ex(const void *d_in, void *d_out, const debig_stream
     if (n == 0) return 0;
     if (waves_per_stream == 0) waves_per_stream = auto_waves_per_stream(n);
     const int mixed = waves_per_stream == DEBIG_WAVES_LARGE4_SMALL1 || waves_per_stream == DEBIG_WAVES_LARGE4_SMALL2;
-    if (!mixed && waves_per_stream != 1 && waves_per_stream != 2 && waves_per_stream != 4)
+    if (!mixed && waves_per_stream != 1 && waves_per_stream != 2 && waves_per_stream != 4 && waves_per_stream != 8)
         return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)hip_stream;
     CodeTabs *ft = fixed_tables(s);

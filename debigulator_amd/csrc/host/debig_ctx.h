@@ -32,6 +32,7 @@ static inline uint64_t debig_align16(uint64_t x) { return (x + 15u) & ~(uint64_t
  * profiles/r01_mw_sweep.txt). */
 static inline uint32_t debig_pick_waves(const debig_stream *desc, uint32_t n)
 {
+    if (n <= 256u) return 8u;
     if (n <= 512u) return 4u;
     if (n <= 1024u) return 2u;
     uint32_t n_large = 0;

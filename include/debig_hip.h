@@ -91,13 +91,13 @@ int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d
 
 /* Same, choosing how many 64-lane wavefronts cooperate on ONE stream:
  *   1          one wavefront per stream (best for many thousands of streams)
- *   2, 4       one stream per workgroup of that many wavefronts (best for a few large
- *              streams, e.g. big PNG images)
+ *   2, 4, 8    one stream per workgroup of that many wavefronts (best for a few large
+ *              streams, e.g. big PNG images; 8 uses half-size input segments)
  *   DEBIG_WAVES_LARGE4_SMALL1 / _SMALL2
  *              by stream: large ones (>= 256 KiB of input or >= 1 MiB of recipient) 4-wide,
  *              the others 1- or 2-wide, as two launches that run side by side (an internal
  *              HIP stream; hip_stream continues only after both)
- *   0          the library picks from n: n <= 512: 4; n <= 1024: 2; else 1 (never a mixed
+ *   0          the library picks from n: n <= 256: 8; n <= 512: 4; n <= 1024: 2; else 1 (never a mixed
  *              mode: stream sizes are in device memory).  debig_hip_inflate_batch does this.
  *              The environment variable DEBIG_WAVES_PER_STREAM (1, 2, 4, 0x41, 0x42)
  *              replaces this choice, for measurements.

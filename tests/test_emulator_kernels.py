@@ -55,6 +55,28 @@ def test_cfg2_streams(emu, oracle, kind):
             assert r.n_windows > 0 and r.n_rounds / r.n_windows < 6  # speculation converges fast
 
 
+def test_eight_wavefront_kernel_with_half_size_segments(emu, oracle):
+    """debig_inflate_mw_kernel<8>: 512 threads, 34-byte segments, round 0 starting one segment
+    early.  A dynamic stream that crosses windows and the 32 KiB tile, plus damaged streams."""
+    raw, plain = workload.make_stream("dynamic", 9, 98304)
+    rng = random.Random(8)
+    raws, caps = [raw], [98305]
+    for it in range(8):
+        data = bytes(rng.choice(b"abcdefgh \n") for _ in range(rng.randint(100, 5000)))
+        r = bytearray(zlib.compress(data, 6)[2:-4])
+        if it % 2:
+            r[rng.randrange(len(r))] ^= 1 << rng.randrange(8)
+        raws.append(bytes(r))
+        caps.append(len(data) * 3 + 64)
+    outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=8, out_misalign=7)
+    assert (outs[0][0], outs[0][1]) == (1, 98304) and outs[0][2] == plain.tobytes()
+    for raw_i, cap, (good, final, out, r) in zip(raws[1:], caps[1:], outs[1:]):
+        eg, ef, eo, st = oracle.inflate(raw_i, cap, want_stats=True)
+        if st.ub_flags & (0x10 | 0x02):
+            continue
+        assert (good, final, out) == (eg, ef, eo)
+
+
 def test_multi_wavefront_kernel_crosses_windows_and_tiles(emu):
     """One 64 KiB dynamic-Huffman stream through the 4-wavefront kernel: several 17 KiB input
     windows, the 16 KiB output tile rolls over, matches are resolved by all wavefronts."""

@@ -46,9 +46,9 @@ def _payload(rng, n, kind):
     return (bytes(rng.getrandbits(8) for _ in range(rng.randint(1, 40))) * (n // 2 + 1))[:n]
 
 
-# wavefronts per stream: debig_inflate_kernel, debig_inflate_mw_kernel<2>, <4>, and the two
+# wavefronts per stream: debig_inflate_kernel, debig_inflate_mw_kernel<2>, <4>, <8>, and the two
 # mixed modes (large streams 4-wide beside small ones 1- / 2-wide, include/debig_hip.h)
-WIDTHS = (1, 2, 4, 0x41, 0x42)
+WIDTHS = (1, 2, 4, 8, 0x41, 0x42)
 
 
 def _check(oracle, gpu_device, raws, caps, widths=WIDTHS, **kw):

@@ -13,7 +13,8 @@ kinds = (sys.argv[1] if len(sys.argv) > 1 else "fixed,dynamic,png").split(",")
 sizes = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "65536,1048576").split(",")]
 counts = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1,16,64,256,1024,4096").split(",")]
 MAX_BYTES = 512 << 20
-print(f"{'kind':8s} {'size':>9s} {'n':>5s} " + " ".join(f"{'w=%d GB/s' % w:>11s}" for w in (1, 2, 4)), flush=True)
+WIDTHS = (1, 2, 4, 8)
+print(f"{'kind':8s} {'size':>9s} {'n':>5s} " + " ".join(f"{'w=%d GB/s' % w:>11s}" for w in WIDTHS), flush=True)
 for kind in ([] if "mixed" in sys.argv else kinds):
     for size in sizes:
         nmax = max(c for c in counts if c * size <= MAX_BYTES)
@@ -26,7 +27,7 @@ for kind in ([] if "mixed" in sys.argv else kinds):
             caps = [max(size + 1, len(r)) for r in raws]
             b = DeviceBatch.from_streams(raws, caps)
             row = []
-            for w in (1, 2, 4):
+            for w in WIDTHS:
                 b.d_out.zero_()
                 for _ in range(2):
                     b.launch(waves_per_stream=w)

@@ -52,6 +52,8 @@ extern "C" int emu_inflate_batch_cls(const void *in, void *out, const debig_stre
         EMU_LAUNCH(debig_inflate_mw_kernel<2>, grid, 128, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft, cls);
     else if (nw == 4)
         EMU_LAUNCH(debig_inflate_mw_kernel<4>, grid, 256, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft, cls);
+    else if (nw == 8)
+        EMU_LAUNCH(debig_inflate_mw_kernel<8>, grid, 512, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft, cls);
     else
         return -1;
     return 0;
