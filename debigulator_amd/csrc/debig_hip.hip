@@ -23,20 +23,29 @@ static inline uint32_t pick_grid(uint32_t n, uint32_t per_cu)
     return n < cap ? n : cap;
 }
 
-// BTYPE 1 tables, built once per device by a tiny kernel and then only copied into LDS
-static CodeTabs *g_fixed_tabs[64];
-static CodeTabs *fixed_tables(hipStream_t s)
+// BTYPE 1 tables, built once per device by a tiny kernel and then only copied into LDS.  Two
+// images: the single-wavefront kernel and the multi-wavefront kernels use different direct
+// table widths (TabCfg<NW>).
+struct FixedTabs {
+    uint32_t *one, *mw;
+};
+static FixedTabs g_fixed_tabs[64];
+static const FixedTabs *fixed_tables(hipStream_t s)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (g_fixed_tabs[dev]) return g_fixed_tabs[dev];
-    CodeTabs *p = nullptr;
-    if (hipMalloc(&p, sizeof(CodeTabs)) != hipSuccess) return nullptr;
-    hipLaunchKernelGGL(debig_fixed_tables_kernel, dim3(1), dim3(64), 0, s, p);
+    FixedTabs *f = &g_fixed_tabs[dev];
+    if (f->one && f->mw) return f;
+    uint32_t *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, sizeof(CodeTabsT<TabCfg<1>::PBL>)) != hipSuccess) return nullptr;
+    if (hipMalloc(&b, sizeof(CodeTabsT<TabCfg<2>::PBL>)) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(debig_fixed_tables_kernel<1>, dim3(1), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(debig_fixed_tables_kernel<2>, dim3(1), dim3(64), 0, s, b);
     // later launches may use other streams: make the tables globally visible first
     if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
-    g_fixed_tabs[dev] = p;
-    return p;
+    f->one = a;
+    f->mw = b;
+    return f;
 }
 
 static CkTables *g_ck_tabs[64];
@@ -100,21 +109,21 @@ static uint32_t auto_waves_per_stream(uint32_t n)
 }
 
 static int launch_inflate(uint32_t width, uint32_t cls, hipStream_t s, const void *d_in, void *d_out,
-                          const debig_stream *d_streams, debig_result *d_results, uint32_t n, const CodeTabs *ft)
+                          const debig_stream *d_streams, debig_result *d_results, uint32_t n, const FixedTabs *tabs)
 {
     const uint32_t grid = n; /* one workgroup per stream: the hardware scheduler balances lengths */
     if (width == 1)
         hipLaunchKernelGGL(debig_inflate_kernel, dim3(grid), dim3(64), 0, s, (const uint8_t *)d_in,
-                           (uint8_t *)d_out, d_streams, d_results, n, ft, cls);
+                           (uint8_t *)d_out, d_streams, d_results, n, tabs->one, cls);
     else if (width == 2)
         hipLaunchKernelGGL(debig_inflate_mw_kernel<2>, dim3(grid), dim3(128), 0, s, (const uint8_t *)d_in,
-                           (uint8_t *)d_out, d_streams, d_results, n, ft, cls);
+                           (uint8_t *)d_out, d_streams, d_results, n, tabs->mw, cls);
     else if (width == 4)
         hipLaunchKernelGGL(debig_inflate_mw_kernel<4>, dim3(grid), dim3(256), 0, s, (const uint8_t *)d_in,
-                           (uint8_t *)d_out, d_streams, d_results, n, ft, cls);
+                           (uint8_t *)d_out, d_streams, d_results, n, tabs->mw, cls);
     else
         hipLaunchKernelGGL(debig_inflate_mw_kernel<8>, dim3(grid), dim3(512), 0, s, (const uint8_t *)d_in,
-                           (uint8_t *)d_out, d_streams, d_results, n, ft, cls);
+                           (uint8_t *)d_out, d_streams, d_results, n, tabs->mw, cls);
     return (int)hipGetLastError();
 }
 
@@ -148,7 +157,7 @@ int debig_hip_inflate_batch_ex(const void *d_in, void *d_out, const debig_stream
     if (!mixed && waves_per_stream != 1 && waves_per_stream != 2 && waves_per_stream != 4 && waves_per_stream != 8)
         return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)hip_stream;
-    CodeTabs *ft = fixed_tables(s);
+    const FixedTabs *ft = fixed_tables(s);
     if (!ft) return (int)hipErrorOutOfMemory;
     if (!mixed) return launch_inflate(waves_per_stream, DEBIG_CLASS_ALL, s, d_in, d_out, d_streams, d_results, n, ft);
 

@@ -28,10 +28,10 @@ static int emu_inflate_1(const void *in, void *out, const debig_stream *streams,
                                  debig_result *results, uint32_t n, uint32_t grid, uint32_t cls)
 {
     if (grid == 0 || grid > n) grid = n;
-    static CodeTabs *ft = nullptr;
+    static uint32_t *ft = nullptr;
     if (!ft) {
-        ft = (CodeTabs *)calloc(1, sizeof(CodeTabs));
-        EMU_LAUNCH(debig_fixed_tables_kernel, 1, 64, ft);
+        ft = (uint32_t *)calloc(1, sizeof(CodeTabsT<TabCfg<1>::PBL>));
+        EMU_LAUNCH(debig_fixed_tables_kernel<1>, 1, 64, ft);
     }
     EMU_LAUNCH(debig_inflate_kernel, grid, 64, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft, cls);
     return 0;
@@ -43,10 +43,10 @@ extern "C" int emu_inflate_batch_cls(const void *in, void *out, const debig_stre
 {
     if (nw == 1) return emu_inflate_1(in, out, streams, results, n, grid, cls);
     if (grid == 0 || grid > n) grid = n;
-    static CodeTabs *ft = nullptr;
+    static uint32_t *ft = nullptr;
     if (!ft) {
-        ft = (CodeTabs *)calloc(1, sizeof(CodeTabs));
-        EMU_LAUNCH(debig_fixed_tables_kernel, 1, 64, ft);
+        ft = (uint32_t *)calloc(1, sizeof(CodeTabsT<TabCfg<2>::PBL>));
+        EMU_LAUNCH(debig_fixed_tables_kernel<2>, 1, 64, ft);
     }
     if (nw == 2)
         EMU_LAUNCH(debig_inflate_mw_kernel<2>, grid, 128, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft, cls);
