@@ -159,6 +159,16 @@ static uint32_t gz_member_header(const uint8_t *p, uint64_t avail, uint64_t *hdr
     return DEBIG_GZ_OK;
 }
 
+DEBIG_API uint32_t debig_gz_parse_header(const uint8_t *p, uint64_t avail, uint64_t *header_len, uint64_t *member_size)
+{
+    uint64_t hl = 0, bs = 0;
+    if (!p) return DEBIG_GZ_E_HEADER;
+    uint32_t st = gz_member_header(p, avail, &hl, &bs);
+    if (header_len) *header_len = st == DEBIG_GZ_OK ? hl : 0;
+    if (member_size) *member_size = st == DEBIG_GZ_OK ? bs : 0;
+    return st;
+}
+
 typedef struct gz_item { /* one member in flight */
     uint32_t file;
     uint64_t payload;    /* file offset of its DEFLATE data            */

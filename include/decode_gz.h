@@ -65,6 +65,12 @@ enum {
     DEBIG_GZ_E_ISIZE = 6,       /* ISIZE of a member does not match                        */
     DEBIG_GZ_E_TRAILING = 7     /* garbage after the last member (output is complete)      */
 };
+/* Host-only helper (no GPU involved): parse ONE gzip member header at p (avail bytes left in
+ * the file).  Returns DEBIG_GZ_OK, DEBIG_GZ_E_HEADER or DEBIG_GZ_E_TRUNCATED; on success
+ * *header_len is where the DEFLATE data starts and *member_size the total member size taken
+ * from a BGZF "BC" extra subfield (0 when there is none).  What debig_gunzip_batch uses. */
+uint32_t debig_gz_parse_header(const uint8_t *p, uint64_t avail, uint64_t *header_len, uint64_t *member_size);
+
 int debig_gunzip_batch(const uint8_t *const *inputs, const uint64_t *input_sizes,
                        uint8_t *const *outs, const uint64_t *out_caps, uint64_t *out_sizes,
                        uint32_t *status, uint32_t *n_members, uint32_t n);

@@ -55,3 +55,36 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(N.DebigStream) == 56 == STREAM_DTYPE.itemsize
     assert ctypes.sizeof(N.DebigResult) == 72 == RESULT_DTYPE.itemsize
     assert ctypes.sizeof(N.DebigPngImage) == 56
+
+
+def test_gzip_header_parser_host_only(native_lib):
+    """debig_gz_parse_header (include/decode_gz.h): RFC 1952 member headers with every optional
+    field, the BGZF size subfield, truncation and rejects -- pure host code, no GPU needed."""
+    import ctypes as C
+    import struct
+    import zlib
+
+    f = native_lib.debig_gz_parse_header
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+
+    def parse(b, avail=None):
+        hl, ms = C.c_uint64(77), C.c_uint64(77)
+        st = f(b, len(b) if avail is None else avail, C.byref(hl), C.byref(ms))
+        return st, hl.value, ms.value
+
+    base = bytes([31, 139, 8, 0, 0, 0, 0, 0, 0, 255])
+    assert parse(base + b"xx") == (0, 10, 0)
+    # FEXTRA (two subfields, the second is BGZF's BC with BSIZE = 0x1234) + FNAME + FCOMMENT + FHCRC
+    extra = b"XY\x03\x00abc" + b"BC\x02\x00\x34\x12"
+    h = bytes([31, 139, 8, 2 | 4 | 8 | 16, 0, 0, 0, 0, 0, 255]) + struct.pack("<H", len(extra)) + extra + b"name\0" + b"a comment\0"
+    h += struct.pack("<H", zlib.crc32(h) & 0xFFFF)
+    assert parse(h + b"payload") == (0, len(h), 0x1234 + 1)
+    # every truncation point of that header is reported as truncated, never read past
+    for cut in range(10, len(h)):
+        assert parse(h, cut)[0] == 2, cut
+    assert parse(h[:9], 9)[0] == 2 and parse(b"", 0)[0] == 2
+    # rejects: wrong magic, wrong method, reserved flag bits
+    assert parse(b"PK" + base[2:])[0] == 1
+    assert parse(bytes([31, 139, 7]) + base[3:])[0] == 1
+    assert parse(bytes([31, 139, 8, 0x20]) + base[4:])[0] == 1
