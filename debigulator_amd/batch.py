@@ -7,6 +7,7 @@ compute is the hand-written HIP kernel behind `debig_hip_inflate_batch`
 `recipient_size`, and back come `final_recipient_size` and `good`.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -56,10 +57,26 @@ def pack_streams(raws, caps, in_align=16, out_align=16, in_skew=0, out_skew=0, p
     return in_arena, streams, _align(out_off, 16) + 64
 
 
+def plan_batch(streams):
+    """Dispatch plan of one launch, the same rule as csrc/host/debig_ctx.h: debig_plan_batch.
+    Workgroups start in descriptor order; a batch of 513..1024 streams whose largest quarter
+    holds at least half of the input bytes is launched longest first, 4 wavefronts wide.
+    -> (order or None, waves_per_stream or 0)."""
+    n = len(streams)
+    if n <= 512 or n > 1024:
+        return None, 0
+    lens = streams["in_len"].astype(np.int64)
+    order = np.lexsort((np.arange(n), -lens))
+    total, top = int(lens.sum()), int(lens[order[: n // 4]].sum())
+    if total and top * 2 >= total:
+        return order, 4
+    return None, 0
+
+
 class DeviceBatch:
     """Streams resident in HBM, ready to be inflated any number of times."""
 
-    def __init__(self, in_arena, streams, out_bytes, device="cuda:0"):
+    def __init__(self, in_arena, streams, out_bytes, device="cuda:0", plan=False):
         import torch
 
         self.torch = torch
@@ -68,14 +85,17 @@ class DeviceBatch:
         self.streams_host = streams
         self.d_in = torch.from_numpy(in_arena).to(self.device)
         self.d_out = torch.zeros(out_bytes, dtype=torch.uint8, device=self.device)
-        self.d_streams = torch.from_numpy(streams.view(np.uint8).reshape(-1)).to(self.device)
+        # streams_host stays in the caller's order; the device copy may be in dispatch order
+        self.order, self.planned_waves = plan_batch(streams) if plan else (None, 0)
+        dev_streams = streams if self.order is None else np.ascontiguousarray(streams[self.order])
+        self.d_streams = torch.from_numpy(dev_streams.view(np.uint8).reshape(-1)).to(self.device)
         self.d_results = torch.zeros(self.n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
         self.lib = N.lib()
 
     @classmethod
-    def from_streams(cls, raws, caps, device="cuda:0", **kw):
+    def from_streams(cls, raws, caps, device="cuda:0", plan=False, **kw):
         in_arena, streams, out_bytes = pack_streams(raws, caps, **kw)
-        return cls(in_arena, streams, out_bytes, device)
+        return cls(in_arena, streams, out_bytes, device, plan=plan)
 
     def launch(self, stream=None, waves_per_stream=0):
         """Asynchronous: one kernel launch on `stream` (default: torch's current stream).
@@ -84,14 +104,22 @@ class DeviceBatch:
         torch = self.torch
         if stream is None:
             stream = torch.cuda.current_stream(self.device)
+        if waves_per_stream == 0 and self.planned_waves and not os.environ.get("DEBIG_WAVES_PER_STREAM"):
+            waves_per_stream = self.planned_waves
         rc = self.lib.debig_hip_inflate_batch_ex(self.d_in.data_ptr(), self.d_out.data_ptr(),
                                                  self.d_streams.data_ptr(), self.d_results.data_ptr(),
                                                  self.n, waves_per_stream, C.c_void_p(stream.cuda_stream))
         N.check(rc, "debig_hip_inflate_batch_ex")
 
     def results(self):
+        """results in the caller's stream order"""
         self.torch.cuda.synchronize(self.device)
-        return self.d_results.cpu().numpy().view(RESULT_DTYPE)
+        raw = self.d_results.cpu().numpy().view(RESULT_DTYPE)
+        if self.order is None:
+            return raw
+        out = np.empty_like(raw)
+        out[self.order] = raw
+        return out
 
     def output(self, i, res=None):
         res = self.results() if res is None else res

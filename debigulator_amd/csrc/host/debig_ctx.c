@@ -41,3 +41,43 @@ void debig_ctx_release(uint32_t thread_id)
     buf_free(&c->crcs);
     buf_free(&c->copies);
 }
+
+int debig_launch_inflate_planned(debig_ctx *c, const void *d_in_arena, const debig_stream *desc,
+                                 debig_result *res, uint32_t n)
+{
+    if (n == 0) return 0;
+    int rc = 0, permuted = 0;
+    uint32_t *order = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+    const uint32_t waves = debig_plan_batch(desc, n, order, &permuted);
+    debig_stream *sorted = NULL;
+    debig_result *tmp = NULL;
+    const debig_stream *up = desc;
+    debig_result *down = res;
+    if (permuted) {
+        sorted = (debig_stream *)malloc((size_t)n * sizeof(debig_stream));
+        tmp = (debig_result *)malloc((size_t)n * sizeof(debig_result));
+        if (sorted && tmp) {
+            for (uint32_t k = 0; k < n; k++) sorted[k] = desc[order[k]];
+            up = sorted;
+            down = tmp;
+        } else {
+            permuted = 0; /* out of host memory for the plan: launch in the caller's order */
+        }
+    }
+    const uint32_t w = permuted ? waves : debig_pick_waves(desc, n);
+    if ((rc = debig_devbuf_reserve(&c->desc, (uint64_t)n * sizeof(debig_stream))) ||
+        (rc = debig_devbuf_reserve(&c->res, (uint64_t)n * sizeof(debig_result))) ||
+        (rc = debig_hip_memcpy_h2d(c->desc.ptr, up, (uint64_t)n * sizeof(debig_stream), NULL)) ||
+        (rc = debig_hip_inflate_batch_ex(d_in_arena, c->out.ptr, (const debig_stream *)c->desc.ptr,
+                                         (debig_result *)c->res.ptr, n, w, NULL)) ||
+        (rc = debig_hip_memcpy_d2h(down, c->res.ptr, (uint64_t)n * sizeof(debig_result), NULL)) ||
+        (rc = debig_hip_stream_sync(NULL))) {
+        /* fall through to the cleanup */
+    } else if (permuted) {
+        for (uint32_t k = 0; k < n; k++) res[order[k]] = tmp[k];
+    }
+    free(order);
+    free(sorted);
+    free(tmp);
+    return rc;
+}

@@ -3,6 +3,7 @@
 #define DEBIG_CTX_H
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include "debig_hip.h"
 
 #define DEBIG_MAX_THREADS 10 /* reference: INFLATE_MAX_THREADS / PNG_DECODER_MAX_THREADS */
@@ -40,5 +41,51 @@ static inline uint32_t debig_pick_waves(const debig_stream *desc, uint32_t n)
         n_large += desc[i].in_len >= DEBIG_LARGE_IN_BYTES || desc[i].out_cap >= DEBIG_LARGE_OUT_BYTES;
     return (n_large != 0 && n_large <= 256u) ? DEBIG_WAVES_LARGE4_SMALL1 : 1u;
 }
+
+/* Dispatch plan for one inflate launch.  Workgroups start in descriptor order, so for a batch
+ * of 513..1024 streams whose sizes are strongly skewed (the largest quarter of the streams
+ * holds at least half of the input bytes) the descriptors are launched LONGEST FIRST and 4
+ * wavefronts wide: the long streams start at once and the short ones fill in behind them
+ * (config 3, 1024 sample PNGs: 49.1 ms uniform 2-wide -> 42.7 ms).  Uniform batches of that
+ * size stay 2-wide in their own order (4-wide would lose a third).  order[k] = index of the
+ * descriptor to launch k-th (only written when *permuted is set). */
+typedef struct debig_len_idx {
+    uint64_t len;
+    uint32_t idx;
+} debig_len_idx;
+static int debig_len_idx_desc(const void *a, const void *b)
+{
+    const debig_len_idx *x = (const debig_len_idx *)a, *y = (const debig_len_idx *)b;
+    if (x->len != y->len) return x->len < y->len ? 1 : -1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+static inline uint32_t debig_plan_batch(const debig_stream *desc, uint32_t n, uint32_t *order, int *permuted)
+{
+    *permuted = 0;
+    const uint32_t waves = debig_pick_waves(desc, n);
+    if (n <= 512u || n > 1024u || !order) return waves;
+    debig_len_idx *v = (debig_len_idx *)malloc((size_t)n * sizeof(debig_len_idx));
+    if (!v) return waves;
+    uint64_t total = 0, top = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        v[i].len = desc[i].in_len;
+        v[i].idx = i;
+        total += desc[i].in_len;
+    }
+    qsort(v, n, sizeof(debig_len_idx), debig_len_idx_desc);
+    for (uint32_t k = 0; k < n / 4u; k++) top += v[k].len;
+    const int skewed = total != 0 && top * 2u >= total;
+    if (skewed)
+        for (uint32_t k = 0; k < n; k++) order[k] = v[k].idx;
+    free(v);
+    *permuted = skewed;
+    return skewed ? 4u : waves;
+}
+
+/* One planned inflate launch (debig_plan_batch): uploads the descriptors (longest first when the
+ * plan says so), launches on the default stream over in_arena -> c->out, brings the results back
+ * in the CALLER'S order and synchronises.  c->desc / c->res are (re)sized here.  0 or an error. */
+int debig_launch_inflate_planned(debig_ctx *c, const void *d_in_arena, const debig_stream *desc,
+                                 debig_result *res, uint32_t n);
 
 #endif

@@ -294,15 +294,9 @@ DEBIG_API int debig_gunzip_batch(const uint8_t *const *inputs, const uint64_t *i
             desc[k].out_cap = it->out_rel <= out_caps[i] ? out_caps[i] - it->out_rel : 0;
             desc[k].flags = DEBIG_STREAM_NO_REF_GATES;
         }
-        if ((rc = debig_devbuf_reserve(&c->desc, (uint64_t)m * sizeof(debig_stream))) ||
-            (rc = debig_devbuf_reserve(&c->res, (uint64_t)m * sizeof(debig_result))) ||
-            (rc = debig_devbuf_reserve(&c->spans, (uint64_t)m * sizeof(debig_span))) ||
+        if ((rc = debig_devbuf_reserve(&c->spans, (uint64_t)m * sizeof(debig_span))) ||
             (rc = debig_devbuf_reserve(&c->crcs, (uint64_t)m * sizeof(uint32_t))) ||
-            (rc = debig_hip_memcpy_h2d(c->desc.ptr, desc, (uint64_t)m * sizeof(debig_stream), NULL)) ||
-            (rc = debig_hip_inflate_batch_ex(c->files.ptr, c->out.ptr, (const debig_stream *)c->desc.ptr,
-                                             (debig_result *)c->res.ptr, m, debig_pick_waves(desc, m), NULL)) ||
-            (rc = debig_hip_memcpy_d2h(res, c->res.ptr, (uint64_t)m * sizeof(debig_result), NULL)) ||
-            (rc = debig_hip_stream_sync(NULL)))
+            (rc = debig_launch_inflate_planned(c, c->files.ptr, desc, res, m)))
             goto done;
         for (uint32_t k = 0; k < m; k++) {
             spans[k].off = desc[k].out_off;

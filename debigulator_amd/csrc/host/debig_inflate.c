@@ -83,12 +83,7 @@ int debig_inflate_batch_impl(uint8_t *const *outs, const uint64_t *out_caps, uin
     /* streams with NULL arguments are still launched as zero-length (they fail the gates) */
     for (uint32_t i = 0; i < n; i++)
         if (skip[i]) { desc[i].in_len = 0; desc[i].out_cap = 0; }
-    if ((rc = debig_hip_memcpy_h2d(c->desc.ptr, desc, (uint64_t)n * sizeof(debig_stream), NULL))) goto done;
-    if ((rc = debig_hip_inflate_batch_ex(c->in.ptr, c->out.ptr, (const debig_stream *)c->desc.ptr,
-                                         (debig_result *)c->res.ptr, n, debig_pick_waves(desc, n), NULL)))
-        goto done;
-    if ((rc = debig_hip_memcpy_d2h(res, c->res.ptr, (uint64_t)n * sizeof(debig_result), NULL))) goto done;
-    if ((rc = debig_hip_stream_sync(NULL))) goto done;
+    if ((rc = debig_launch_inflate_planned(c, c->in.ptr, desc, res, n))) goto done;
     for (uint32_t i = 0; i < n && !rc; i++) {
         if (skip[i]) continue;
         if (res[i].final_set) {

@@ -330,12 +330,7 @@ done_bulk:
     free(copies);
     free(file_off);
     if (rc) goto done;
-    if ((rc = debig_hip_memcpy_h2d(c->desc.ptr, desc, (uint64_t)n * sizeof(debig_stream), NULL))) goto done;
-    if ((rc = debig_hip_inflate_batch_ex(c->in.ptr, c->out.ptr, (const debig_stream *)c->desc.ptr,
-                                         (debig_result *)c->res.ptr, n, debig_pick_waves(desc, n), NULL)))
-        goto done;
-    if ((rc = debig_hip_memcpy_d2h(res, c->res.ptr, (uint64_t)n * sizeof(debig_result), NULL))) goto done;
-    if ((rc = debig_hip_stream_sync(NULL))) goto done;
+    if ((rc = debig_launch_inflate_planned(c, c->in.ptr, desc, res, n))) goto done;
     /* de-filter the images whose stream inflated (the first filter byte is checked on the
      * device together with every other row's; the reference checks it first, :847-858) */
     uint32_t nimg = 0;

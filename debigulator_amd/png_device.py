@@ -48,7 +48,7 @@ class DevicePngBatch:
         in_arena, streams, out_bytes = pack_streams(raws, ests, p2=p2)
         # palettes live behind the stream arena
         pal_base = out_bytes
-        self.inflate = DeviceBatch(in_arena, streams, out_bytes + 768 * n + 64, device)
+        self.inflate = DeviceBatch(in_arena, streams, out_bytes + 768 * n + 64, device, plan=True)
         img = (N.DebigPngImage * n)()
         off = 0
         self.rgba_off = []

@@ -88,3 +88,23 @@ def test_gzip_header_parser_host_only(native_lib):
     assert parse(b"PK" + base[2:])[0] == 1
     assert parse(bytes([31, 139, 7]) + base[3:])[0] == 1
     assert parse(bytes([31, 139, 8, 0x20]) + base[4:])[0] == 1
+
+
+def test_dispatch_plan_for_skewed_batches():
+    """debigulator_amd.batch.plan_batch (same rule as csrc/host/debig_ctx.h: debig_plan_batch):
+    only batches of 513..1024 streams whose largest quarter holds half of the input are
+    reordered longest first, and results come back in the caller's order."""
+    import numpy as np
+    from debigulator_amd.batch import STREAM_DTYPE, plan_batch
+
+    def mk(lens):
+        s = np.zeros(len(lens), dtype=STREAM_DTYPE)
+        s["in_len"] = lens
+        return s
+
+    assert plan_batch(mk([1000] * 1024)) == (None, 0)                 # uniform: own order, library default
+    assert plan_batch(mk([10**6] * 100 + [1000] * 100))[0] is None      # too few streams
+    order, waves = plan_batch(mk([1000, 10**6, 1000, 1000] * 200))     # 800 streams, a quarter of them long
+    assert waves == 4 and list(order[:3]) == [1, 5, 9] and sorted(order) == list(range(800))
+    assert plan_batch(mk([1000, 10**6] * 400)) == (None, 0)             # half long: not skewed enough
+    assert plan_batch(mk([1000] * 2000))[0] is None                     # beyond the range

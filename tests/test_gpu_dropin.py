@@ -59,6 +59,22 @@ def test_inflate_batch_big_batch_with_a_few_large_streams(api):
             assert out == plain.tobytes(), i
 
 
+def test_inflate_batch_skewed_sizes_are_dispatched_longest_first(api):
+    """A batch of 600 streams in which a quarter is large goes through debig_plan_batch
+    (descriptors launched longest first, 4 wavefronts wide, results returned in the caller's
+    order): every stream must come back at its own index."""
+    from debigulator_amd import workload
+
+    small = workload.make_streams("dynamic", 8, 3000)
+    large = workload.make_streams("fixed", 3, 400000)
+    pairs = [large[i % 3] if i % 4 == 1 else small[i % 8] for i in range(600)]
+    res = api.inflate_batch([p[0] for p in pairs], [len(p[1]) + 1 for p in pairs])
+    for i, ((good, final, out), (_, plain)) in enumerate(zip(res, pairs)):
+        assert good == 1 and final == len(plain), i
+        if i % 37 == 0 or i % 4 == 1 and i < 40:
+            assert out == plain.tobytes(), i
+
+
 def test_inflate_argument_gates(api):
     import ctypes as C
     from debigulator_amd import _native as N
