@@ -49,6 +49,26 @@ def test_raw_inflate_fuzz(oracle, ref):
     assert truncated > 10  # the tail rule Q2 really fires and both sides agree on it
 
 
+def test_flush_heavy_streams(oracle, ref):
+    """Encoders that flush every few bytes (PNG writers flushing per row): hundreds of blocks,
+    empty stored blocks in between, fixed and dynamic codes.  The GPU kernels treat this pattern
+    specially (short-block probe), so the oracle is pinned to the reference on it as well."""
+    rng = random.Random(78)
+    for it in range(250):
+        data = bytes(rng.choice(b"abcdefgh \n") for _ in range(rng.randint(20, 5000)))
+        c = zlib.compressobj(rng.choice([0, 1, 6, 9]), zlib.DEFLATED, -15, 9,
+                             rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE]))
+        raw, i, maxchunk = b"", 0, rng.choice([3, 20, 60, 200])
+        while i < len(data):
+            n = rng.randint(1, maxchunk)
+            raw += c.compress(data[i:i + n])
+            i += n
+            raw += c.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_BLOCK]))
+        raw += c.flush()
+        cap = max(len(data) + 1, len(raw))
+        assert oracle.inflate(raw, cap) == ref.inflate(raw, cap), it
+
+
 def test_gates(oracle, ref):
     raw = zlib.compress(b"hello world " * 40)[2:-4]
     # (recipient_size between C and D is excluded: the asserts-on reference aborts there, Q12)
