@@ -1,31 +1,40 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json metric on BASELINE config 2 (configs[1]).
+"""bench.py -- BASELINE.json metric: decompressed GB/s + fraction of the HBM roofline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg5]
 
-Workload (per rank; SURVEY.md 8d "cfg2"): 4096 fixed-Huffman streams + 4096
-stored-block streams, every stream inflating to one 64 KiB block; streams are
-generated deterministically (tools/streamgen.c, seed 0xDEB16 + global stream index).
-One "step" = one pass of the hot path (ONE launch of the batched inflate kernel through
-the C-ABI, include/debig_hip.h) over the whole batch, inputs already resident in HBM.
+--config cfg2 (default; BASELINE config 2 = configs[1], SURVEY.md 8d "cfg2"): per GPU 4096
+  fixed-Huffman streams + 4096 stored-block streams, every stream inflating to one 64 KiB
+  block, generated deterministically (tools/streamgen.c, seed 0xDEB16 + global stream index).
+  Weak scaling: per-GPU work is fixed as N grows.
+--config cfg5 (BASELINE config 5 = configs[4]): --members (default 65536) gzip members of
+  1 MiB (text-like payload, dynamic Huffman, ratio about 2.5:1), member i -> GPU i mod N.
+  Strong scaling: the total is fixed.  The payload bytes are inflated by the same kernel; the
+  CRC-32 trailer of every member is verified on the GPU outside the timed region.
 
-  value      decompressed GB/s, whole job  = sum over ranks of D bytes / max-over-ranks time
-  roofline   that launch: algorithmic bytes C + D of the batch / average launch duration
-             (events on the launch stream); --variants adds each stream kind timed alone
-  cpu_baseline  the compiled reference (oracle/_ref, single thread) or, if that prebuilt
-             library is absent, the oracle port -- timed on a bounded sample of the same streams
+One "step" = one pass of the hot path (the batched inflate through the C-ABI,
+include/debig_hip.h) over this rank's whole shard, inputs already resident in HBM.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): one process per GPU; rank 0
-builds the shard map (stream id -> rank, offsets) and broadcasts it over RCCL; every
-rank inflates its own shard; no payload collective (weak scaling: per-GPU work fixed).
+  value         decompressed GB/s, whole job = sum over ranks of D bytes / max-over-ranks time
+  roofline      the whole batch: algorithmic bytes C + D per step / average step duration measured
+                with events on the launch stream.  cfg2 also carries roofline_huffman and
+                roofline_stored: each stream kind launched alone, timed the same way.
+  cpu_baseline  the compiled reference (oracle/_ref; or the oracle port if that prebuilt library
+                is absent) on the host cores: one thread per kind, blended, and all cores.
+
+Multi-GPU: `--gpus N` with N > 1 started WITHOUT a torch.distributed environment spawns
+`python -m torch.distributed.run --nproc-per-node N` on itself (before anything touches the
+GPU) and passes rank 0's JSON line through; started by torch.distributed.run it is a rank.
+Rank 0 builds the shard map (stream id -> rank) and broadcasts it (RCCL); every rank inflates
+its own shard; no payload collective.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -33,64 +42,201 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is achievable
 STREAMS_PER_KIND = 4096
 STREAM_BYTES = 65536
+CFG5_MEMBERS = 65536
+CFG5_MEMBER_BYTES = 1 << 20
+CFG5_DISTINCT = 512  # distinct member seeds in the whole job; member i has seed i mod 512
 
 
-def cpu_baseline(sample_fixed, sample_stored):
-    """Reference (or oracle port) single-thread throughput on a bounded sample."""
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg5"])
+    ap.add_argument("--streams", type=int, default=STREAMS_PER_KIND, help="cfg2: streams per kind per rank")
+    ap.add_argument("--members", type=int, default=CFG5_MEMBERS, help="cfg5: gzip members in the whole job")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", type=int, default=64, help="streams per kind checked byte for byte")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
+                    "rehearse the N>1 code path on one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 100 if args.config == "cfg2" else 5
+    if args.warmup is None:
+        args.warmup = 5 if args.config == "cfg2" else 1
+    return args
+
+
+def spawn_ranks(args):
+    """Parent of an N-rank run: never imports torch, never touches the GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def host_description():
+    model = "?"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {"cpu_model": model, "nproc": os.cpu_count() or 1, "usable_cores": usable}
+
+
+# ---------------------------------------------------------------- CPU baseline (checker side)
+def _cpu_engine():
     from oracle import binding
 
-    kind = "port"
-    eng = None
     if binding.ref_available("A"):
         try:
-            eng = binding.Reference("A")
-            kind = "reference"
+            return binding.Reference("A"), "reference"
         except OSError:
-            eng = None
-    if eng is None:
-        eng = binding.Oracle()
-    nbytes = 0
-    passes = 0
-    t0 = time.perf_counter()
-    while True:  # whole passes over the sample until ~10 s of single-thread CPU work
-        for raw, plain in sample_fixed + sample_stored:
-            cap = max(len(plain) + 1, len(raw))
-            out = eng.inflate(raw, cap)
-            assert out[0] == 1 and out[1] == len(plain)
-            nbytes += len(plain)
+            pass
+    return binding.Oracle(), "port"
+
+
+def _cpu_pass(eng, sample):
+    n = 0
+    for raw, cap, want in sample:
+        out = eng.inflate(raw, cap)
+        assert out[0] == 1 and out[1] == want
+        n += want
+    return n
+
+
+def _cpu_timed(eng, sample, budget_s, max_passes=64):
+    nbytes, passes, t0 = 0, 0, time.perf_counter()
+    while True:
+        nbytes += _cpu_pass(eng, sample)
         passes += 1
-        if time.perf_counter() - t0 > 10.0 or passes >= 8:
+        if time.perf_counter() - t0 > budget_s or passes >= max_passes:
             break
     dt = time.perf_counter() - t0
+    return nbytes / dt / 1e9, passes, dt
+
+
+def _cpu_worker(job):
+    sample, budget_s = job
+    eng, _ = _cpu_engine()
+    t0 = time.perf_counter()
+    nbytes = 0
+    while time.perf_counter() - t0 < budget_s:
+        nbytes += _cpu_pass(eng, sample)
+    return nbytes, time.perf_counter() - t0
+
+
+def cpu_baseline(samples, label):
+    """samples: {kind: [(raw, recipient_size, decompressed size)]}.  Reference (or port) on the host
+    cores: one thread per kind, one thread blended, and every usable core (one process each)."""
+    import multiprocessing as mp
+
+    eng, kind = _cpu_engine()
+    host = host_description()
+    per_kind = {}
+    for k, smp in samples.items():
+        v, passes, dt = _cpu_timed(eng, smp, 4.0)
+        per_kind[k] = {"value": v, "passes": passes, "seconds": round(dt, 2)}
+    blend = [x for smp in samples.values() for x in smp]
+    v1, passes, dt1 = _cpu_timed(eng, blend, 5.0)
+    cores = max(1, host["usable_cores"])
+    all_core = None
+    try:
+        ctx = mp.get_context("spawn")  # never fork a process that holds a GPU context
+        with ctx.Pool(cores) as pool:
+            t0 = time.perf_counter()
+            outs = pool.map(_cpu_worker, [(blend, 5.0)] * cores)
+            wall = time.perf_counter() - t0
+        all_core = {"value": sum(o[0] for o in outs) / max(o[1] for o in outs) / 1e9, "cores": cores,
+                    "seconds": round(wall, 2)}
+    except Exception as e:  # a report, never a reason to lose the GPU number
+        all_core = {"value": None, "cores": cores, "error": str(e)[:200]}
     return {
-        "value": nbytes / dt / 1e9,
+        "value": v1,
         "unit": "GB/s decompressed",
         "cores": 1,
         "kind": kind,
-        "sample": f"{len(sample_fixed)} fixed-Huffman + {len(sample_stored)} stored streams of 64 KiB "
-                  f"(same generator), {passes} pass(es), 1 thread, {dt:.1f} s",
+        "sample": f"{label}; whole passes, 1 thread, {dt1:.1f} s ({passes} passes)",
+        "per_kind_1thread": per_kind,
+        "all_cores": all_core,
+        "host": host,
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=STREAMS_PER_KIND, help="streams per kind per rank")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", type=int, default=64, help="streams per kind checked against the generator")
-    ap.add_argument("--variants", action="store_true", help="also time each stream kind alone (untimed extra)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
-                    "the N>1 code path on one GPU)")
-    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    args = ap.parse_args()
+def run_cpu_baseline(args, world, samples, label):
+    """rank 0 at N=1 only, and BEFORE this process initialises the GPU: the all-core leg starts
+    worker processes, which a process holding a GPU context must not do on this pool."""
+    if args.no_cpu_baseline or world != 1:
+        return None
+    try:
+        return cpu_baseline(samples, label)
+    except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+        return {"value": None, "unit": "GB/s decompressed", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
 
+
+# ---------------------------------------------------------------- GPU side
+def time_launches(torch, fn, steps):
+    """average duration of fn() over `steps` launches, events on torch's current stream (the
+    stream the kernels are launched on)"""
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    e[0].record()
+    for k in range(steps):
+        fn()
+        e[k + 1].record()
+    torch.cuda.synchronize()
+    return sum(e[k].elapsed_time(e[k + 1]) for k in range(steps)) / steps
+
+
+def pmc_traffic(kernel_sources_digest, scale):
+    """HBM bytes per launch from the PMC passes of this same command (tools/pmc_traffic.sh +
+    tools/pmc_summary.py -> profiles/pmc_traffic.json).  Only reported when that file was made
+    from the kernel sources that are being timed now; otherwise null."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if tj.get("kernel_sources_sha256") != kernel_sources_digest:
+            return None, "profiles/pmc_traffic.json is from other kernel sources: not reported"
+        return tj["bytes_per_launch"] * scale, tj.get("source", "profiles/pmc_traffic.json")
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
+def kernel_sources_digest():
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "debigulator_amd", "csrc", "*.inc")) +
+                    glob.glob(os.path.join(ROOT, "debigulator_amd", "csrc", "*.hip"))):
+        h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -102,102 +248,173 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group(args.backend)
-    torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     coll_dev = dev if args.backend == "nccl" else "cpu"  # where collective tensors live
+    if world > 1:
+        torch.cuda.set_device(local_rank)
 
-    from debigulator_amd import workload
-    from debigulator_amd.batch import DeviceBatch
-
-    per = args.streams
-    # ---- shard map: rank 0 builds it, RCCL broadcasts it (the only collective on the path)
-    from debigulator_amd import shard
-
-    smap = shard.broadcast_shard_map(world * per, coll_dev, dist if world > 1 else None)
-    mine = shard.my_streams(smap, rank)  # global stream ids of this rank
-    assert len(mine) == per
-
-    # ---- synthesise this rank's shard (deterministic) and park it in HBM
-    ncpu = max(1, min(16, (os.cpu_count() or 8) // max(1, min(world, 8))))
     from concurrent.futures import ThreadPoolExecutor
 
-    pairs_keep = {}
-    for kind in ("fixed", "stored"):
+    from debigulator_amd import shard, workload
+    from debigulator_amd.batch import DeviceBatch
+
+    ncpu = max(1, min(16, (os.cpu_count() or 8) // max(1, min(world, 8))))
+    cfg5 = args.config == "cfg5"
+
+    # ---- shard map: rank 0 builds it, RCCL broadcasts it (the only collective on the path)
+    n_units = args.members if cfg5 else world * args.streams
+    if world > 1:
+        smap = shard.broadcast_shard_map(n_units, coll_dev, dist)
+        mine = shard.my_streams(smap, rank)  # global ids of this rank's units, in local order
+    else:
+        mine = np.arange(n_units, dtype=np.int64)  # one rank owns everything; no GPU call yet (see below)
+
+    kinds = {}
+    if not cfg5:
+        # ---- cfg2: this rank's shard, synthesised deterministically, parked in HBM as ONE batch:
+        # the long-running Huffman streams first, the stored ones behind them
+        assert len(mine) == args.streams
+        per = args.streams
+        pairs_keep = {}
+        for kind in ("fixed", "stored"):
+            with ThreadPoolExecutor(ncpu) as ex:
+                pairs_keep[kind] = list(ex.map(lambda g: workload.make_stream(kind, int(g), STREAM_BYTES), mine))
+        all_pairs = pairs_keep["fixed"] + pairs_keep["stored"]
+        raws = [p[0] for p in all_pairs]
+        caps = [max(STREAM_BYTES + 1, len(r)) for r in raws]
+        samples = {k: [(p[0], max(STREAM_BYTES + 1, len(p[0])), STREAM_BYTES) for p in pairs_keep[k][:128]]
+                   for k in ("fixed", "stored")}
+        sample_label = "128 fixed-Huffman + 128 stored streams of 64 KiB from the timed batch"
+        cpu_line = run_cpu_baseline(args, world, samples, sample_label)
+        torch.cuda.set_device(local_rank)
+        batch = DeviceBatch.from_streams(raws, caps, device=dev)
+        c_kind = {k: sum(len(p[0]) for p in v) for k, v in pairs_keep.items()}
+        c_bytes = sum(c_kind.values())
+        d_bytes = STREAM_BYTES * len(raws)
+        unit_bytes = STREAM_BYTES
+
+        def verify():
+            res = batch.results()
+            assert (res["good"] == 1).all(), "a stream failed"
+            assert (res["final_size"] == STREAM_BYTES).all(), "wrong size"
+            for base in (0, per):
+                for i in range(base, base + min(args.verify, per)):
+                    assert batch.output(i, res) == all_pairs[i][1].tobytes(), f"stream {i} differs"
+            return res
+
+        # each kind alone (its own descriptors over the same arenas would change nothing: own batch)
+        for kind, lo in (("fixed", 0), ("stored", per)):
+            kinds[kind] = (DeviceBatch.from_streams(raws[lo:lo + per], caps[lo:lo + per], device=dev),
+                           c_kind[kind], per * STREAM_BYTES)
+        workload_name = (f"cfg2: per GPU {per} fixed-Huffman + {per} stored DEFLATE streams, 64 KiB each, one "
+                         f"batch per step (one 64 KiB block per stream; stored = 65535+1 byte blocks), "
+                         f"seed 0xDEB16+i")
+    else:
+        # ---- cfg5: member i -> GPU i mod N.  Distinct payloads: seed = i mod 512; this rank's
+        # members cycle through its 512/N seeds, replicated ON THE DEVICE into one arena per
+        # direction (every member has its own input and output bytes in HBM)
+        assert args.members % world == 0
+        n_mine = len(mine)
+        uniq = max(1, min(n_mine, CFG5_DISTINCT // world))
         with ThreadPoolExecutor(ncpu) as ex:
-            pairs_keep[kind] = list(ex.map(lambda g: workload.make_stream(kind, int(g), STREAM_BYTES), mine))
-    # ONE batch = this rank's whole shard: the long-running Huffman streams first, the stored
-    # ones behind them (workgroups are dispatched in stream order)
-    all_pairs = pairs_keep["fixed"] + pairs_keep["stored"]
-    raws = [p[0] for p in all_pairs]
-    caps = [max(STREAM_BYTES + 1, len(r)) for r in raws]
-    batch = DeviceBatch.from_streams(raws, caps, device=dev)
-    c_fixed = sum(len(p[0]) for p in pairs_keep["fixed"])
-    c_stored = sum(len(p[0]) for p in pairs_keep["stored"])
-    c_bytes = c_fixed + c_stored
-    d_bytes = STREAM_BYTES * len(raws)
+            pairs = list(ex.map(lambda g: workload.make_stream("dynamic", int(g) % CFG5_DISTINCT, CFG5_MEMBER_BYTES),
+                                mine[:uniq]))
+        members = [workload.gzip_member(r, p) for r, p in pairs]
+        raws_u = [m[10:-8] for m in members]  # decode_gz's host side: 10-byte header, 8-byte trailer
+        caps_u = [max(CFG5_MEMBER_BYTES + 1, len(r)) for r in raws_u]
+        from debigulator_amd.batch import pack_streams
+
+        samples = {"gzip_dynamic": [(raws_u[i], caps_u[i], CFG5_MEMBER_BYTES) for i in range(min(8, uniq))]}
+        sample_label = f"{min(8, uniq)} of the timed gzip members (1 MiB each, dynamic Huffman)"
+        cpu_line = run_cpu_baseline(args, world, samples, sample_label)
+        torch.cuda.set_device(local_rank)
+        in_block, st_block, out_block = pack_streams(raws_u, caps_u)
+        reps = (n_mine + uniq - 1) // uniq
+        streams = np.tile(st_block, reps)[:n_mine].copy()
+        k = np.arange(n_mine) // uniq
+        streams["in_off"] += (k * len(in_block)).astype(np.uint64)
+        streams["out_off"] += (k * out_block).astype(np.uint64)
+        batch = DeviceBatch.__new__(DeviceBatch)
+        batch.torch, batch.device, batch.n, batch.streams_host = torch, torch.device(dev), n_mine, streams
+        blk = torch.from_numpy(in_block).to(dev)
+        batch.d_in = blk.repeat(reps)
+        batch.d_out = torch.zeros(out_block * reps, dtype=torch.uint8, device=dev)
+        batch.order, batch.planned_waves = None, 0
+        batch.d_streams = torch.from_numpy(streams.view(np.uint8).reshape(-1)).to(dev)
+        from debigulator_amd.batch import RESULT_DTYPE
+        from debigulator_amd import _native
+
+        batch.d_results = torch.zeros(n_mine * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        batch.lib = _native.lib()
+        c_bytes = int(streams["in_len"].sum())
+        d_bytes = CFG5_MEMBER_BYTES * n_mine
+        unit_bytes = CFG5_MEMBER_BYTES
+
+        def verify():
+            import struct
+
+            from debigulator_amd.checksum import CRC32, DeviceChecksums
+
+            res = batch.results()
+            assert (res["good"] == 1).all(), "a member failed"
+            assert (res["final_size"] == CFG5_MEMBER_BYTES).all(), "wrong size"
+            spans = [(int(streams[i]["out_off"]), CFG5_MEMBER_BYTES) for i in range(n_mine)]
+            ck = DeviceChecksums(batch.d_out, spans, CRC32)
+            ck.launch()
+            want = np.array([struct.unpack("<I", members[i % uniq][-8:-4])[0] for i in range(n_mine)], dtype=np.uint32)
+            assert (np.asarray(ck.results(), dtype=np.uint32) == want).all(), "a member's CRC-32 differs"
+            for i in sorted({0, n_mine // 2, n_mine - 1}):
+                assert batch.output(i, res) == pairs[i % uniq][1].tobytes(), f"member {i} differs"
+            return res
+
+        workload_name = (f"cfg5: {args.members} gzip members of 1 MiB (text-like, dynamic Huffman), member i -> GPU "
+                         f"i mod {world}; seed 0xDEB16 + (i mod {CFG5_DISTINCT}), each member has its own bytes in HBM")
 
     for _ in range(args.warmup):
         batch.launch()
     torch.cuda.synchronize()
-
-    # ---- bit-exactness gate (untimed): sizes/flags of every stream, bytes of a sample
-    res = batch.results()
-    assert (res["good"] == 1).all(), "a stream failed"
-    assert (res["final_size"] == STREAM_BYTES).all(), "wrong size"
-    for base in (0, per):
-        for i in range(base, base + args.verify):
-            assert batch.output(i, res) == all_pairs[i][1].tobytes(), f"stream {i} differs"
+    res = verify()  # ---- bit-exactness gate (untimed)
 
     # ---- timed region: exactly K steps between barrier+sync on both sides
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev[0].record()
     for k in range(args.steps):
-        ev[k][0].record()
         batch.launch()
-        ev[k][1].record()
+        ev[k + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+    tot = torch.tensor([float(d_bytes), float(c_bytes)], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt_max = float(t.item())
-    launch_ms = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)]))
-
-    variants = None
-    if args.variants and rank == 0:  # untimed extra: each kind launched alone
-        variants = {}
-        for kind, lo, cb in (("fixed_huffman", 0, c_fixed), ("stored", per, c_stored)):
-            sub = DeviceBatch.from_streams(raws[lo:lo + per], caps[lo:lo + per], device=dev)
-            for _ in range(2):
-                sub.launch()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                sub.launch()
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 5
-            variants[kind] = {"kernel_ms": ms, "decompressed_GBps": per * STREAM_BYTES / ms / 1e6,
-                              "roofline_frac": (cb + per * STREAM_BYTES) / ms / 1e6 / HBM_PEAK_GBS}
+    step_ms = float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]))
 
     if rank == 0:
-        value = world * d_bytes * args.steps / dt_max / 1e9
-        alg = c_bytes + d_bytes
-        ach = alg / (launch_ms * 1e-3) / 1e9
-        rf = res[:per]
-        # HBM traffic per launch from the PMC passes of this same command (profiles/pmc_traffic.json,
-        # made by tools/pmc_traffic.sh + tools/pmc_summary.py); null if that file is absent
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            traffic = tj["bytes_per_launch"] * (per / STREAMS_PER_KIND)
-        except (OSError, ValueError, KeyError):
-            pass
+        job_d, job_c = float(tot[0].item()), float(tot[1].item())
+        value = job_d * args.steps / dt_max / 1e9
+        digest = kernel_sources_digest()
+
+        def roof(c, d, ms, what, launches):
+            ach = (c + d) / (ms * 1e-3) / 1e9
+            return {"kernel": what, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_step": c + d,
+                    "avg_step_ms": ms, "decompressed_GBps": d / ms / 1e6, "launches_per_step": launches}
+
+        lps = getattr(batch, "launches_per_step", 1)
+        rl = roof(c_bytes, d_bytes, step_ms, "the step's inflate launch(es) on rank 0 (whole batch)", lps)
+        if not cfg5:
+            tr, src = pmc_traffic(digest, args.streams / STREAMS_PER_KIND)
+            rl["traffic"] = tr
+            if src:
+                rl["traffic_source"] = src
         line = {
             "metric": "decompressed GB/s (whole node) + % HBM roofline, bit-exact vs reference",
             "value": value,
@@ -207,43 +424,42 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if cfg5 else "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"cfg2: per GPU {per} fixed-Huffman + {per} stored DEFLATE streams, 64 KiB each, one "
-                            f"batch = one kernel launch (one 64 KiB block per stream; stored = 65535+1 byte "
-                            f"blocks), seed 0xDEB16+i",
-                "streams_per_gpu": 2 * per,
-                "decompressed_bytes_per_gpu": d_bytes,
-                "compressed_bytes_per_gpu": c_bytes,
-                "fixed_huffman_ratio": per * STREAM_BYTES / c_fixed,
-                "sharding": "round-robin by stream id, shard map broadcast over RCCL, no payload collective",
-                "bit_exact_checked": f"{args.verify} streams per kind byte-for-byte + all sizes/good flags",
-                "avg_spec_rounds_per_window": float(rf["n_rounds"].sum()) / max(1, float(rf["n_windows"].sum())),
+                "workload": workload_name,
+                "units_per_gpu": len(res),
+                "unit_decompressed_bytes": unit_bytes,
+                "decompressed_bytes_job": job_d,
+                "compressed_bytes_job": job_c,
+                "ratio": job_d / job_c,
+                "bit_exact_checked": ("every member's size/good flag + CRC-32 (on the GPU), 3 members byte for byte"
+                                      if cfg5 else f"{min(args.verify, args.streams)} streams per kind byte for byte "
+                                      f"+ all sizes/good flags"),
             },
-            "roofline": {
-                "kernel": "debig_inflate_kernel (the step's only launch)",
-                "bound": "hbm",
-                "achieved": ach,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg,
-                "avg_launch_ms": launch_ms,
-            },
+            "roofline": rl,
         }
-        if variants:
-            line["variants"] = variants
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            try:
-                line["cpu_baseline"] = cpu_baseline(pairs_keep["fixed"], pairs_keep["stored"])
-            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
-                line["cpu_baseline"] = {"value": None, "unit": "GB/s decompressed", "cores": 1, "kind": "port",
-                                        "sample": f"failed: {e}"}
-        print(json.dumps(line))
+        if world > 1:
+            line["config"]["sharding"] = (f"round-robin by unit id over {world} ranks, shard map broadcast "
+                                          f"({args.backend}), no payload collective")
+        nw = res["n_windows"].astype(np.float64).sum()
+        if nw > 0:
+            line["config"]["avg_spec_rounds_per_window"] = float(res["n_rounds"].astype(np.float64).sum() / nw)
+        # each stream kind alone (untimed extras, rank 0)
+        for kind, (sub, cb, db) in kinds.items():
+            for _ in range(2):
+                sub.launch()
+            ms = time_launches(torch, sub.launch, 10)
+            r = sub.results()
+            assert (r["good"] == 1).all()
+            name = "roofline_huffman" if kind == "fixed" else "roofline_stored"
+            line[name] = roof(cb, db, ms, f"{kind} streams launched alone ({len(r)} x 64 KiB)",
+                              getattr(sub, "launches_per_step", 1))
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

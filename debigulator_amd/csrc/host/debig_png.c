@@ -163,6 +163,11 @@ static void png_walk(png_state *st, const uint8_t *in, uint64_t in_size, uint64_
             at += 13;
             r->est = (uint64_t)(uint32_t)(r->w * r->h * 4u + r->h + 1u);
             if ((uint64_t)(uint32_t)(r->w * r->h * 4u) != rgba_size) goto fail;
+            /* The reference does this arithmetic in uint32 (:965-985), so dimensions whose
+             * 4wh + h + 1 wraps can pass the size check with a small buffer; its de-filter
+             * loop then runs into the end of that buffer and reports out_good = 0 (:1459).
+             * The kernels iterate the real w and h: such a file must never reach them. */
+            if ((uint64_t)r->w * (uint64_t)r->h * 4u + (uint64_t)r->h + 1u != r->est) goto fail;
             if (r->ct != 2 && r->ct != 3 && r->ct != 6) goto fail;
             if (r->w < 1 || r->h < 1) goto fail;
             if ((uint64_t)(uint32_t)(r->w * r->h * 4u + r->h + 1u + INFLATE_HASHMAPS_SIZE) > st->wm_size) goto fail;
@@ -206,11 +211,34 @@ static void png_walk(png_state *st, const uint8_t *in, uint64_t in_size, uint64_
     if (!ready) goto fail; /* P6: inflate only runs when a non-IDAT chunk follows the IDATs */
     r->packed = packed;
     r->zsize = (uint64_t)(uint32_t)((uint32_t)packed - 4u); /* uint32 arithmetic as in :816 */
+    /* inflate()'s own argument gates (src/inflate.c:826-844) fail these before a byte is read:
+     * do not reserve arena space for them (an IDAT payload under 4 bytes wraps zsize to 4 GiB) */
+    if (packed > 0xffffffffull || r->zsize < 5 || r->zsize > r->est) goto fail;
     r->ok = 1;
     return;
 fail:
     parsed_free(r);
     r->ok = 0;
+}
+
+/* Host-only view of the container walk: would decode_png hand this file to inflate, and with
+ * which sizes?  (0 wherever the reference returns out_good = 0 before inflate runs.) */
+DEBIG_API int debig_png_probe(const uint8_t *in, const uint64_t in_size, const uint64_t rgba_values_size,
+                              const uint32_t dpng_working_memory_size, uint32_t *out_width, uint32_t *out_height,
+                              uint64_t *out_recipient_size, uint64_t *out_zlib_size)
+{
+    png_state st;
+    png_parsed r;
+    memset(&st, 0, sizeof st);
+    st.wm_size = dpng_working_memory_size;
+    png_walk(&st, in, in_size, rgba_values_size, &r);
+    if (out_width) *out_width = r.ok ? r.w : 0;
+    if (out_height) *out_height = r.ok ? r.h : 0;
+    if (out_recipient_size) *out_recipient_size = r.ok ? r.est : 0;
+    if (out_zlib_size) *out_zlib_size = r.ok ? r.zsize : 0;
+    const int ok = r.ok;
+    parsed_free(&r);
+    return ok;
 }
 
 static int strict_mode(void)
@@ -258,6 +286,11 @@ DEBIG_API int debig_decode_png_batch(const uint8_t *const *inputs, const uint64_
             rgba_total += debig_align16(out_sizes[i]) + 16;
             if (P[i].ct == 2 && !strict) rgba_total += debig_align16(out_sizes[i]) + 16; /* P3 replay: second buffer */
         }
+    }
+    {
+        uint32_t n_ok = 0;
+        for (uint32_t i = 0; i < n; i++) n_ok += P[i].ok != 0;
+        if (n_ok == 0) goto done; /* nothing passed the container walk: no device work at all */
     }
     /* ---- bulk bytes go to HBM once: whole files; chunk CRCs and the IDAT concatenation
      *      happen there (the host has only looked at chunk headers) */

@@ -43,6 +43,7 @@ def lib():
         L.sg_wrap_gzip.argtypes = [vp, u64, vp, u64, vp, u64]
         L.sg_wrap_png.restype = u64
         L.sg_wrap_png.argtypes = [vp, u64, vp, u64, u32, u32, u32, vp, u32, u32, vp, u64]
+        L.sg_payload_image_mix.argtypes = [u64, u32, u32, u32, u32, u32, u32, vp]
         L.sg_png_filter.argtypes = [vp, u32, u32, u32, u32, vp]
         L.sg_crc32.restype = u32
         L.sg_crc32.argtypes = [u32, vp, u64]
@@ -110,13 +111,20 @@ def gzip_member(raw, plain):
     return dst[:n].tobytes()
 
 
+CFG4_NOISE = (1, 2, 48)  # config 4: amplitude 1, amplitude 2 for HI/256 of the samples -> ratio about 3:1
+
+
 def make_png(seed, w, h, ct=6, ftype=4, noise=8, enc="dynamic", idat_chunk=65536, palette=None):
     """Synthetic PNG: smooth image + noise, forward-filtered, own DEFLATE encoder.
+    noise: amplitude, or a (lo, hi, hi_per_256) mix (CFG4_NOISE lands at S/C of about 3).
     Returns (png bytes, defiltered pixel bytes [h, w*bpp])."""
     L = lib()
     bpp = {6: 4, 2: 3, 3: 1}[ct]
     pix = np.zeros(w * h * bpp, dtype=np.uint8)
-    L.sg_payload_image(seed, w, h, bpp, noise, pix.ctypes.data)
+    if isinstance(noise, tuple):
+        L.sg_payload_image_mix(seed, w, h, bpp, noise[0], noise[1], noise[2], pix.ctypes.data)
+    else:
+        L.sg_payload_image(seed, w, h, bpp, noise, pix.ctypes.data)
     filt = np.zeros(h * (w * bpp + 1), dtype=np.uint8)
     L.sg_png_filter(pix.ctypes.data, w, h, bpp, ftype, filt.ctypes.data)
     raw = encode(enc, filt)

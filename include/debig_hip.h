@@ -50,6 +50,10 @@ typedef struct debig_stream {
  * callers outside the reference's API whose input span is not "one stream", e.g. a gzip
  * member followed by further members (debig_gunzip_batch). */
 #define DEBIG_STREAM_NO_REF_GATES 1u
+/* Test hook (fault injection, never set by the host layer): the multi-wavefront match resolve
+ * gives up at its first idle poll instead of after DEBIG_RESOLVE_IDLE_BOUND of them, so the
+ * DEBIG_E_INTERNAL path can be exercised on ordinary data. */
+#define DEBIG_STREAM_FAULT_INJECT_IDLE 0x80000000u
 
 /* status codes in debig_result.status (0 = success) */
 enum {
@@ -62,7 +66,9 @@ enum {
     DEBIG_E_DIST_SYMBOL = 6,          /* distance symbol > 29 (inflate.c:1809)                  */
     DEBIG_E_DIST_TOO_FAR = 7,         /* distance beyond start of output (inflate.c:1843)       */
     DEBIG_E_OUTPUT_FULL = 8,          /* output would exceed recipient_size (ref: overflow/assert) */
-    DEBIG_E_LITLEN_286_287 = 9        /* symbols 286/287 (ref: reads past its table)            */
+    DEBIG_E_LITLEN_286_287 = 9,       /* symbols 286/287 (ref: reads past its table)            */
+    DEBIG_E_INTERNAL = 10             /* a kernel-internal guard tripped (bounded wait exhausted); never
+                                         expected -- the stream is reported failed, not silently wrong */
 };
 
 typedef struct debig_result {

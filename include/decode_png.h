@@ -52,6 +52,19 @@ int debig_decode_png_batch(const uint8_t *const *inputs, const uint64_t *input_s
                            uint8_t *const *outs, const uint64_t *out_sizes, uint8_t *goods,
                            uint32_t n, const uint32_t thread_id);
 
+/* Extension, host only (no GPU work): the container walk of decode_png (reference
+ * src/decode_png.c:730-1367) on its own.  Returns 1 when decode_png would hand the file to
+ * inflate() -- signature, chunk layout, IHDR/PLTE/IDAT rules, rgba_values_size == 4wh, working
+ * memory large enough -- and then reports the image size, the recipient size (4wh + h + 1)
+ * and the zlib payload size it would pass; 0 wherever the reference sets out_good = 0 first.
+ * Chunk CRCs are NOT checked here (they are verified on the GPU by the decode calls).
+ * Image dimensions whose 4wh + h + 1 does not fit 32 bits are rejected: the reference's
+ * uint32 arithmetic wraps there and its de-filter loop ends in out_good = 0. */
+int debig_png_probe(const uint8_t *compressed_input, const uint64_t compressed_input_size,
+                    const uint64_t rgba_values_size, const uint32_t dpng_working_memory_size,
+                    uint32_t *out_width, uint32_t *out_height, uint64_t *out_recipient_size,
+                    uint64_t *out_zlib_size);
+
 #ifdef __cplusplus
 }
 #endif

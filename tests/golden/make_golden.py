@@ -28,8 +28,44 @@ def sha(b):
     return hashlib.sha256(bytes(b)).hexdigest()
 
 
+def corrupt_corpus():
+    """6. damaged raw streams through reference build B in a child process (tests/ref_worker.py):
+    how the reference FAILS (src/inflate.c:1427-1434 bad code-length code, :1809 distance symbol,
+    :1843-1852 too-far with the partial final size, :465-473 no code, :949 stored LEN/NLEN).  Cases on
+    which the reference is in undefined behaviour (oracle ub_flags) or dies are left out."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ref_worker import RefWorker, corrupt_cases
+
+    orc = binding.Oracle()
+    w = RefWorker()
+    keep, quota = [], {"good": 60, "fail_partial": 130, "fail_empty": 20}
+    for raw, cap in corrupt_cases(20261004, 3000):
+        g, f, o, st = orc.inflate(raw, cap, want_stats=True)
+        if st.ub_flags:
+            continue
+        r = w.inflate("B", raw, cap)
+        if r is None:
+            continue
+        good, final, digest = r
+        cls = "good" if good else ("fail_partial" if final else "fail_empty")
+        if quota[cls] == 0:
+            continue
+        quota[cls] -= 1
+        # a recipient just large enough: nothing the reference produced is cut off by it
+        small = max((final or 0) + 1, len(raw)) + 16
+        assert w.inflate("B", raw, small) == r
+        keep.append({"raw_hex": raw.hex(), "recipient_size": small, "good": good, "final": final,
+                     "out_sha256": digest, "oracle": "B", "class": cls})
+    w.close()
+    assert sum(quota.values()) == 0, quota
+    json.dump(keep, open(os.path.join(HERE, "corpus_corrupt.json"), "w"))
+    print("corpus_corrupt.json:", len(keep), "cases; reference deaths:", w.crashes)
+
+
 def main():
     binding.build(ref=True)
+    if "--only-corrupt" in sys.argv:
+        return corrupt_corpus()
     A = binding.Reference("A")  # silent, asserts on (canonical)
     B = binding.Reference("B")  # silent, asserts off (inputs on which A aborts)
 
@@ -118,6 +154,7 @@ def main():
         pngs.append({"seed": 1000 + j, "w": w, "h": h, "ct": ct, "ftype": ft, "enc": enc, "png_hex": png.hex(),
                      "good": int(good), "rgba_sha256": sha(out.tobytes())})
     json.dump(pngs, open(os.path.join(HERE, "png_synth.json"), "w"))
+    corrupt_corpus()
     print("golden fixtures written:", sorted(os.listdir(HERE)))
 
 

@@ -108,3 +108,57 @@ def test_dispatch_plan_for_skewed_batches():
     assert waves == 4 and list(order[:3]) == [1, 5, 9] and sorted(order) == list(range(800))
     assert plan_batch(mk([1000, 10**6] * 400)) == (None, 0)             # half long: not skewed enough
     assert plan_batch(mk([1000] * 2000))[0] is None                     # beyond the range
+
+
+def _png_file(w, h, ct, idat_payload, extra=b""):
+    import struct
+    import zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+    ihdr = struct.pack(">IIBBBBB", w, h, 8, ct, 0, 0, 0)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + extra + chunk(b"IDAT", idat_payload) + chunk(b"IEND", b"")
+
+
+def test_png_probe_rejects_wrapped_dimensions_host_only(native_lib, oracle):
+    """w*h*4 is uint32 arithmetic in the reference (src/decode_png.c:965-985), so
+    w=32769, h=32768 'needs' a 128 KiB buffer.  The reference ends with out_good = 0 (its de-filter
+    loop runs into the end of the buffer, :1459); the product must reject the file on the host --
+    its kernels iterate the real w and h.  Pure host code: no GPU needed."""
+    import ctypes as C
+    import zlib
+
+    f = native_lib.debig_png_probe
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+
+    def probe(png, rgba_size, wm=120_000_000):
+        w, h, est, z = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint64()
+        ok = f(png, len(png), rgba_size, wm, C.byref(w), C.byref(h), C.byref(est), C.byref(z))
+        return ok, w.value, h.value, est.value, z.value
+
+    # a well-formed small file is accepted, with the sizes the reference computes
+    filt = b"".join(b"\x00" + bytes(range(16)) for _ in range(4))
+    zl = zlib.compress(filt, 6)
+    good_png = _png_file(4, 4, 6, zl)
+    ok, w, h, est, z = probe(good_png, 64)
+    assert (ok, w, h, est, z) == (1, 4, 4, 4 * 4 * 4 + 4 + 1, len(zl) - 2 - 4)
+    assert oracle.decode_png(good_png, rgba_size=64)[0] == 1
+    assert probe(good_png, 63)[0] == 0  # rgba_values_size must be exactly 4wh
+
+    # wrapped: (32769 * 32768 * 4) mod 2^32 == 131072
+    assert (32769 * 32768 * 4) % (1 << 32) == 131072
+    for (ww, hh, size) in ((32769, 32768, 131072), (65536, 65536, 0), (16385, 65536, 262144)):
+        bad = _png_file(ww, hh, 6, zl)
+        assert probe(bad, size)[0] == 0, (ww, hh)
+        if size:  # the oracle restates the reference: same verdict
+            assert oracle.decode_png(bad, rgba_size=size)[0] == 0
+
+    # an IDAT payload too short for inflate()'s gates (zsize would wrap to ~4 GiB) is refused
+    # before any arena is sized from it
+    for payload in (zl[:2], zl[:3], zl[:5], zl[:6]):
+        tiny = _png_file(4, 4, 6, payload)
+        assert probe(tiny, 64)[0] == 0
+        assert oracle.decode_png(tiny, rgba_size=64)[0] == 0

@@ -37,15 +37,20 @@ def test_cfg3_1024_pngs_resident(gpu_device):
         assert sha(b.rgba(i).tobytes()) == gold[name]["rgba_sha256"], (i, name)
 
 
-def test_cfg4_shape_paeth_rgba(gpu_device, oracle):
-    """all rows Paeth, RGBA, dynamic Huffman, 64 KiB IDAT chunks; 512x512 vs the oracle byte for byte"""
+@pytest.mark.parametrize("noise", [workload.CFG4_NOISE, 24], ids=["ratio3", "ratio1.4"])
+def test_cfg4_shape_paeth_rgba(gpu_device, oracle, noise):
+    """all rows Paeth, RGBA, dynamic Huffman, 64 KiB IDAT chunks; 4 distinct seeds of 512x512 vs
+    the oracle byte for byte.  noise = CFG4_NOISE is BASELINE config 4's data (scanline stream /
+    compressed about 3:1, asserted); 24 is the noisier round-1 data (1.4:1), kept as a second case."""
     from debigulator_amd.png_device import DevicePngBatch
 
     pngs, pix = [], []
     for s in range(4):
-        p, x = workload.make_png(7000 + s, 512, 512, ct=6, ftype=4, noise=24, enc="dynamic", idat_chunk=65536)
+        p, x = workload.make_png(7000 + s, 512, 512, ct=6, ftype=4, noise=noise, enc="dynamic", idat_chunk=65536)
         pngs.append(p)
         pix.append(x)
+        if noise == workload.CFG4_NOISE:
+            assert 2.8 < 512 * (512 * 4 + 1) / len(p) < 3.2
     b = DevicePngBatch(pngs, device=gpu_device)
     b.launch()
     res, ires = b.results()
@@ -64,7 +69,8 @@ def test_cfg4_roundtrip_property_large(gpu_device):
     deflate(filter(pixels)))) == pixels"""
     from debigulator_amd.png_device import DevicePngBatch
 
-    p, x = workload.make_png(7100, 2048, 2048, ct=6, ftype=4, noise=24, enc="dynamic", idat_chunk=65536)
+    p, x = workload.make_png(7100, 2048, 2048, ct=6, ftype=4, noise=workload.CFG4_NOISE, enc="dynamic", idat_chunk=65536)
+    assert 2.8 < 2048 * (2048 * 4 + 1) / len(p) < 3.2  # BASELINE config 4: ratio about 3:1
     b = DevicePngBatch([p, p], device=gpu_device)
     b.launch()
     res, ires = b.results()

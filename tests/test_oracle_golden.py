@@ -31,6 +31,16 @@ def test_zlib_corpus(oracle):
         assert (good, final, sha(out)) == (c["good"], c["final"], c["out_sha256"])
 
 
+def test_corrupt_corpus_failure_semantics(oracle):
+    """reference-made (build B) answers for damaged raw streams: good flag, the PARTIAL final size
+    of a failing stream and the bytes up to it (src/inflate.c:1427-1434, :1809, :1843-1852)"""
+    corpus = json.load(open(os.path.join(GOLD, "corpus_corrupt.json")))
+    assert len(corpus) >= 200 and sum(c["good"] == 0 and bool(c["final"]) for c in corpus) >= 100
+    for c in corpus:
+        good, final, out = oracle.inflate(bytes.fromhex(c["raw_hex"]), c["recipient_size"])
+        assert (good, final, sha(out)) == (c["good"], c["final"], c["out_sha256"])
+
+
 def test_resources_png_and_gz(oracle):
     gold = json.load(open(os.path.join(GOLD, "resources.json")))
     files = sorted(glob.glob(os.path.join(GOLD, "resources", "*.png")))

@@ -127,3 +127,35 @@ def test_png_rejects_agree(oracle, ref):
         if g1:
             assert np.array_equal(o1, o2), it
     assert rejected > 50
+
+
+from ref_worker import RefWorker, corrupt_cases  # noqa: E402
+
+
+def test_corrupted_raw_streams_fail_like_the_reference(oracle, ref):
+    """VERDICT r1 missing-5: HOW the reference fails on damaged raw streams -- bad code-length code
+    (src/inflate.c:1427-1434), distance symbol > 29 (:1809), distance beyond the output with the
+    partial final size (:1843-1852), undecodable bit patterns (:465-473), stored LEN/NLEN (:949) --
+    pinned on the same mutators the GPU suite leans on.  Reference build B (asserts off: build A
+    aborts where B reports), in a child process; cases on which the oracle notes undefined
+    behaviour of the reference (ub_flags) or the reference dies are excluded."""
+    import hashlib
+
+    w = RefWorker()
+    compared = failed = partial = 0
+    try:
+        for it, (raw, cap) in enumerate(corrupt_cases(4242, 1500)):
+            g, f, o, st = oracle.inflate(raw, cap, want_stats=True)
+            if st.ub_flags:
+                continue
+            r = w.inflate("B", raw, cap)
+            if r is None:
+                continue
+            assert (g, f, hashlib.sha256(o).hexdigest()) == r, it
+            compared += 1
+            failed += g == 0
+            partial += g == 0 and bool(f)
+    finally:
+        w.close()
+    assert compared > 800 and failed > 150 and partial > 100, (compared, failed, partial, w.crashes)
+    assert w.crashes < 20, w.crashes

@@ -591,3 +591,23 @@ void sg_payload_image(uint64_t seed, uint32_t w, uint32_t h, uint32_t bpp, uint3
             }
         }
 }
+
+/* Like sg_payload_image, with a finer noise knob: every sample draws its amplitude from
+ * {noise_lo, noise_hi}, noise_hi with probability hi_per_256 / 256.  Used to land config 4's
+ * synthetic PNGs at the compression ratio BASELINE.json asks for (about 3:1). */
+void sg_payload_image_mix(uint64_t seed, uint32_t w, uint32_t h, uint32_t bpp, uint32_t noise_lo,
+                          uint32_t noise_hi, uint32_t hi_per_256, uint8_t *out)
+{
+    uint64_t s = seed;
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            uint64_t v = splitmix64(&s);
+            for (uint32_t k = 0; k < bpp; k++) {
+                uint32_t g = (x * (k + 1) / 4 + y * (4 - k) / 4 + 16 * k);
+                uint32_t r = (uint32_t)((v >> (8 * k)) & 0xff);
+                uint32_t pick = (uint32_t)((v >> (32 + 8 * (k & 3))) & 0xff);
+                uint32_t amp = pick < hi_per_256 ? noise_hi : noise_lo;
+                out[((uint64_t)y * w + x) * bpp + k] = (uint8_t)(g + (amp ? r % (amp + 1) : 0));
+            }
+        }
+}
