@@ -153,7 +153,9 @@ def cpu_baseline(samples, label):
         per_kind[k] = {"value": v, "passes": passes, "seconds": round(dt, 2)}
     blend = [x for smp in samples.values() for x in smp]
     v1, passes, dt1 = _cpu_timed(eng, blend, 5.0)
-    cores = max(1, host["usable_cores"])
+    # the GPU box gives one GPU's job a share of 16 host cores (more worker processes than that
+    # only measure process start-up); nproc of the whole machine is reported beside it
+    cores = max(1, min(host["usable_cores"], 16))
     all_core = None
     try:
         ctx = mp.get_context("spawn")  # never fork a process that holds a GPU context
