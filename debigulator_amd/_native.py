@@ -34,6 +34,8 @@ class DebigPngResult(C.Structure):
     _fields_ = [("good", C.c_uint32), ("bad_row", C.c_uint32)]
 
 
+WAVES_SPLIT = 0x10  # include/debig_hip.h: DEBIG_WAVES_SPLIT
+
 _lib = None
 
 
@@ -60,6 +62,10 @@ def lib():
     L.debig_hip_inflate_batch.argtypes = [vp, vp, vp, vp, u32, vp]
     L.debig_hip_inflate_batch_ex.restype = C.c_int
     L.debig_hip_inflate_batch_ex.argtypes = [vp, vp, vp, vp, u32, u32, vp]
+    L.debig_hip_inflate_batch_ws.restype = C.c_int
+    L.debig_hip_inflate_batch_ws.argtypes = [vp, vp, vp, vp, u32, u32, vp, u64, vp]
+    L.debig_hip_inflate_workspace_bytes.restype = u64
+    L.debig_hip_inflate_workspace_bytes.argtypes = [u64, u32]
     L.debig_hip_png_defilter_batch.restype = C.c_int
     L.debig_hip_png_defilter_batch.argtypes = [vp, vp, vp, vp, u32, vp]
     L.debig_hip_device_count.restype = C.c_int

@@ -91,6 +91,7 @@ class DeviceBatch:
         self.d_streams = torch.from_numpy(dev_streams.view(np.uint8).reshape(-1)).to(self.device)
         self.d_results = torch.zeros(self.n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
         self.lib = N.lib()
+        self.d_ws = None  # token workspace of the scan / LZ77 kernel pair, allocated on first use
 
     @classmethod
     def from_streams(cls, raws, caps, device="cuda:0", plan=False, **kw):
@@ -99,17 +100,27 @@ class DeviceBatch:
 
     def launch(self, stream=None, waves_per_stream=0):
         """Asynchronous: one kernel launch on `stream` (default: torch's current stream).
-        waves_per_stream: 1 (one wavefront per stream), 2 / 4 (one stream per workgroup of
-        that many wavefronts, for few large streams), 0 = library's choice from the batch size."""
+        waves_per_stream: 1 (one wavefront per stream), 2 / 4 / 8 (one stream per workgroup of
+        that many wavefronts, for few large streams), _native.WAVES_SPLIT (scan + LZ77 kernel pair,
+        the throughput path), 0 = library's choice from the batch size."""
         torch = self.torch
         if stream is None:
             stream = torch.cuda.current_stream(self.device)
         if waves_per_stream == 0 and self.planned_waves and not os.environ.get("DEBIG_WAVES_PER_STREAM"):
             waves_per_stream = self.planned_waves
-        rc = self.lib.debig_hip_inflate_batch_ex(self.d_in.data_ptr(), self.d_out.data_ptr(),
+        ws_ptr, ws_bytes = None, 0
+        if waves_per_stream == N.WAVES_SPLIT or (waves_per_stream == 0 and self.n > 1024 and
+                                                 not os.environ.get("DEBIG_WAVES_PER_STREAM")):
+            if self.d_ws is None:  # caller-owned workspace: nothing is allocated inside the call
+                total_in = int(self.streams_host["in_len"].sum())
+                nbytes = int(self.lib.debig_hip_inflate_workspace_bytes(total_in, self.n))
+                self.d_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            ws_ptr, ws_bytes = self.d_ws.data_ptr(), self.d_ws.numel()
+        rc = self.lib.debig_hip_inflate_batch_ws(self.d_in.data_ptr(), self.d_out.data_ptr(),
                                                  self.d_streams.data_ptr(), self.d_results.data_ptr(),
-                                                 self.n, waves_per_stream, C.c_void_p(stream.cuda_stream))
-        N.check(rc, "debig_hip_inflate_batch_ex")
+                                                 self.n, waves_per_stream, ws_ptr, ws_bytes,
+                                                 C.c_void_p(stream.cuda_stream))
+        N.check(rc, "debig_hip_inflate_batch_ws")
 
     def results(self):
         """results in the caller's stream order"""

@@ -7,6 +7,7 @@
 
 #include "inflate_kernel.inc"
 #include "inflate_mw_kernel.inc"
+#include "inflate_split_kernel.inc"
 #include "png_kernel.inc"
 #include "checksum_kernel.inc"
 
@@ -27,7 +28,7 @@ static inline uint32_t pick_grid(uint32_t n, uint32_t per_cu)
 // images: the single-wavefront kernel and the multi-wavefront kernels use different direct
 // table widths (TabCfg<NW>).
 struct FixedTabs {
-    uint32_t *one, *mw;
+    uint32_t *one, *mw, *scan; /* scan: the scan kernel's 16-bit format */
 };
 static FixedTabs g_fixed_tabs[64];
 static const FixedTabs *fixed_tables(hipStream_t s)
@@ -35,16 +36,19 @@ static const FixedTabs *fixed_tables(hipStream_t s)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     FixedTabs *f = &g_fixed_tabs[dev];
-    if (f->one && f->mw) return f;
-    uint32_t *a = nullptr, *b = nullptr;
+    if (f->one && f->mw && f->scan) return f;
+    uint32_t *a = nullptr, *b = nullptr, *c = nullptr;
     if (hipMalloc(&a, sizeof(CodeTabsT<TabCfg<1>::PBL>)) != hipSuccess) return nullptr;
-    if (hipMalloc(&b, sizeof(CodeTabsT<TabCfg<2>::PBL>)) != hipSuccess) return nullptr;
+    if (hipMalloc(&b, sizeof(CodeTabsT<TabCfg<2>::PBL>)) != hipSuccess) { (void)hipFree(a); return nullptr; }
+    if (hipMalloc(&c, sizeof(CodeTabsT<TabCfg<1>::PBL, uint16_t>)) != hipSuccess) { (void)hipFree(a); (void)hipFree(b); return nullptr; }
     hipLaunchKernelGGL(debig_fixed_tables_kernel<1>, dim3(1), dim3(64), 0, s, a);
     hipLaunchKernelGGL(debig_fixed_tables_kernel<2>, dim3(1), dim3(64), 0, s, b);
+    hipLaunchKernelGGL(debig_scan_fixed_tables_kernel, dim3(1), dim3(64), 0, s, c);
     // later launches may use other streams: make the tables globally visible first
     if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
     f->one = a;
     f->mw = b;
+    f->scan = c;
     return f;
 }
 
@@ -105,7 +109,70 @@ static uint32_t auto_waves_per_stream(uint32_t n)
     if (n <= 256u) return 8u;
     if (n <= 512u) return 4u;
     if (n <= 1024u) return 2u;
-    return 1u;
+    return DEBIG_WAVES_SPLIT;
+}
+
+// ---- the scan / LZ77 kernel pair (inflate_split_kernel.inc)
+#define SPLIT_GROUP 16384u /* streams per plan + scan + lz + retry group: they share the workspace */
+static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+// default workspace of callers that bring none (debig_hip_inflate_batch / _ex): one cached
+// allocation per device, DEBIG_WORKSPACE_MB (default 1024) MiB
+struct DefaultWs {
+    void *ptr;
+    uint64_t bytes;
+};
+static DefaultWs g_default_ws[64];
+static const DefaultWs *default_workspace(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    DefaultWs *w = &g_default_ws[dev];
+    if (w->ptr) return w;
+    uint64_t mb = 1024;
+    const char *e = getenv("DEBIG_WORKSPACE_MB");
+    if (e && *e) mb = strtoull(e, nullptr, 0);
+    if (mb == 0) return nullptr;
+    void *p = nullptr;
+    if (hipMalloc(&p, mb << 20) != hipSuccess) return nullptr;
+    w->ptr = p;
+    w->bytes = mb << 20;
+    return w;
+}
+
+// one group of at most SPLIT_GROUP streams: plan, scan, lz, and debig_inflate_kernel for what the
+// pair handed back.  Returns 0, a hipError_t, or -1 when the workspace is too small to try.
+static int launch_split_group(hipStream_t s, const void *d_in, void *d_out, const debig_stream *d_streams,
+                              debig_result *d_results, uint32_t n, const FixedTabs *tabs, void *ws, uint64_t ws_bytes)
+{
+    const uint64_t slots_bytes = align_up((uint64_t)n * sizeof(debig_ws_slot), 256);
+    if (ws_bytes < slots_bytes + (uint64_t)n * 1024u) return -1;
+    const uint64_t rest = ws_bytes - slots_bytes;
+    const uint64_t total_recs = rest / 16u / sizeof(debig_ws_rec);
+    const uint64_t recs_bytes = align_up(total_recs * sizeof(debig_ws_rec), 256);
+    const uint64_t total_rows = (rest - recs_bytes) / 256u;
+    debig_ws_slot *slots = (debig_ws_slot *)ws;
+    debig_ws_rec *recs = (debig_ws_rec *)((uint8_t *)ws + slots_bytes);
+    uint32_t *rows = (uint32_t *)((uint8_t *)ws + slots_bytes + recs_bytes);
+    hipLaunchKernelGGL(debig_split_plan_kernel, dim3(1), dim3(1024), 0, s, d_streams, n, slots, total_rows, total_recs);
+    hipLaunchKernelGGL(debig_scan_kernel, dim3(n), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, n,
+                       tabs->scan, slots, recs, rows);
+    hipLaunchKernelGGL(debig_lz_kernel, dim3(n), dim3(64), 0, s, (uint8_t *)d_out, d_streams, d_results, n,
+                       (const debig_ws_slot *)slots, (const debig_ws_rec *)recs, (const uint32_t *)rows);
+    hipLaunchKernelGGL(debig_inflate_kernel, dim3(n), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams,
+                       d_results, n, tabs->one, DEBIG_CLASS_RETRY);
+    return (int)hipGetLastError();
+}
+
+static int launch_split(hipStream_t s, const void *d_in, void *d_out, const debig_stream *d_streams,
+                        debig_result *d_results, uint32_t n, const FixedTabs *tabs, void *ws, uint64_t ws_bytes)
+{
+    for (uint32_t first = 0; first < n; first += SPLIT_GROUP) {
+        const uint32_t cnt = n - first < SPLIT_GROUP ? n - first : SPLIT_GROUP;
+        int rc = launch_split_group(s, d_in, d_out, d_streams + first, d_results + first, cnt, tabs, ws, ws_bytes);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 static int launch_inflate(uint32_t width, uint32_t cls, hipStream_t s, const void *d_in, void *d_out,
@@ -147,18 +214,37 @@ static SideLane *side_lane(void)
     return l;
 }
 
-int debig_hip_inflate_batch_ex(const void *d_in, void *d_out, const debig_stream *d_streams,
+uint64_t debig_hip_inflate_workspace_bytes(uint64_t total_in_bytes, uint32_t n)
+{
+    // token rows: about 4-5 x the compressed bytes for text-like data (one 256-byte row per symbol
+    // index of a 64-lane window) + per-stream slack for partial windows; records and slots on top
+    const uint32_t group = n < SPLIT_GROUP ? n : SPLIT_GROUP;
+    const uint64_t per_group_in = n ? (total_in_bytes + n - 1) / n * group : 0; /* average streams */
+    return align_up((uint64_t)group * (sizeof(debig_ws_slot) + 24576u) + per_group_in * 9u, 4096);
+}
+
+int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream *d_streams,
                                debig_result *d_results, uint32_t n, uint32_t waves_per_stream,
-                               void *hip_stream)
+                               void *d_workspace, uint64_t workspace_bytes, void *hip_stream)
 {
     if (n == 0) return 0;
     if (waves_per_stream == 0) waves_per_stream = auto_waves_per_stream(n);
     const int mixed = waves_per_stream == DEBIG_WAVES_LARGE4_SMALL1 || waves_per_stream == DEBIG_WAVES_LARGE4_SMALL2;
-    if (!mixed && waves_per_stream != 1 && waves_per_stream != 2 && waves_per_stream != 4 && waves_per_stream != 8)
+    if (!mixed && waves_per_stream != 1 && waves_per_stream != 2 && waves_per_stream != 4 && waves_per_stream != 8 &&
+        waves_per_stream != DEBIG_WAVES_SPLIT)
         return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)hip_stream;
     const FixedTabs *ft = fixed_tables(s);
     if (!ft) return (int)hipErrorOutOfMemory;
+    if (waves_per_stream == DEBIG_WAVES_SPLIT) {
+        if (!d_workspace) {
+            const DefaultWs *w = default_workspace();
+            if (w) { d_workspace = w->ptr; workspace_bytes = w->bytes; }
+        }
+        int rc = d_workspace ? launch_split(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes) : -1;
+        if (rc >= 0) return rc;
+        waves_per_stream = 1; /* no usable workspace: the one-kernel path */
+    }
     if (!mixed) return launch_inflate(waves_per_stream, DEBIG_CLASS_ALL, s, d_in, d_out, d_streams, d_results, n, ft);
 
     // large streams 4-wide on the side stream, small ones beside them on the caller's stream;
@@ -175,6 +261,13 @@ int debig_hip_inflate_batch_ex(const void *d_in, void *d_out, const debig_stream
     if (rc) return rc;
     if ((e = hipStreamWaitEvent(s, l->join, 0)) != hipSuccess) return (int)e;
     return 0;
+}
+
+int debig_hip_inflate_batch_ex(const void *d_in, void *d_out, const debig_stream *d_streams,
+                               debig_result *d_results, uint32_t n, uint32_t waves_per_stream,
+                               void *hip_stream)
+{
+    return debig_hip_inflate_batch_ws(d_in, d_out, d_streams, d_results, n, waves_per_stream, nullptr, 0, hip_stream);
 }
 
 int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d_streams,

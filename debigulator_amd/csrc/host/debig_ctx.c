@@ -40,6 +40,7 @@ void debig_ctx_release(uint32_t thread_id)
     buf_free(&c->spans);
     buf_free(&c->crcs);
     buf_free(&c->copies);
+    buf_free(&c->ws);
 }
 
 int debig_launch_inflate_planned(debig_ctx *c, const void *d_in_arena, const debig_stream *desc,
@@ -65,11 +66,18 @@ int debig_launch_inflate_planned(debig_ctx *c, const void *d_in_arena, const deb
         }
     }
     const uint32_t w = permuted ? waves : debig_pick_waves(desc, n);
+    uint64_t ws_bytes = 0;
+    if (w == DEBIG_WAVES_SPLIT) { /* the throughput path wants a token workspace sized from the input */
+        uint64_t total_in = 0;
+        for (uint32_t i = 0; i < n; i++) total_in += desc[i].in_len;
+        ws_bytes = debig_hip_inflate_workspace_bytes(total_in, n);
+        if (debig_devbuf_reserve(&c->ws, ws_bytes)) ws_bytes = 0; /* no memory: the library's own fallback */
+    }
     if ((rc = debig_devbuf_reserve(&c->desc, (uint64_t)n * sizeof(debig_stream))) ||
         (rc = debig_devbuf_reserve(&c->res, (uint64_t)n * sizeof(debig_result))) ||
         (rc = debig_hip_memcpy_h2d(c->desc.ptr, up, (uint64_t)n * sizeof(debig_stream), NULL)) ||
-        (rc = debig_hip_inflate_batch_ex(d_in_arena, c->out.ptr, (const debig_stream *)c->desc.ptr,
-                                         (debig_result *)c->res.ptr, n, w, NULL)) ||
+        (rc = debig_hip_inflate_batch_ws(d_in_arena, c->out.ptr, (const debig_stream *)c->desc.ptr,
+                                         (debig_result *)c->res.ptr, n, w, ws_bytes ? c->ws.ptr : NULL, ws_bytes, NULL)) ||
         (rc = debig_hip_memcpy_d2h(down, c->res.ptr, (uint64_t)n * sizeof(debig_result), NULL)) ||
         (rc = debig_hip_stream_sync(NULL))) {
         /* fall through to the cleanup */

@@ -17,6 +17,7 @@ typedef struct debig_devbuf {
 typedef struct debig_ctx {
     debig_devbuf in, out, desc, res, rgba, img, imgres;
     debig_devbuf files, spans, crcs, copies; /* PNG: whole files, chunk spans, their CRCs, IDAT gather list */
+    debig_devbuf ws; /* token workspace of the scan / LZ77 kernel pair (DEBIG_WAVES_SPLIT) */
 } debig_ctx;
 
 debig_ctx *debig_ctx_get(uint32_t thread_id);
@@ -39,7 +40,7 @@ static inline uint32_t debig_pick_waves(const debig_stream *desc, uint32_t n)
     uint32_t n_large = 0;
     for (uint32_t i = 0; i < n; i++)
         n_large += desc[i].in_len >= DEBIG_LARGE_IN_BYTES || desc[i].out_cap >= DEBIG_LARGE_OUT_BYTES;
-    return (n_large != 0 && n_large <= 256u) ? DEBIG_WAVES_LARGE4_SMALL1 : 1u;
+    return (n_large != 0 && n_large <= 256u) ? DEBIG_WAVES_LARGE4_SMALL1 : DEBIG_WAVES_SPLIT;
 }
 
 /* Dispatch plan for one inflate launch.  Workgroups start in descriptor order, so for a batch

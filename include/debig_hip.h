@@ -113,9 +113,30 @@ int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d
 #define DEBIG_WAVES_AUTO 0u
 #define DEBIG_WAVES_LARGE4_SMALL1 0x41u
 #define DEBIG_WAVES_LARGE4_SMALL2 0x42u
+/*   DEBIG_WAVES_SPLIT
+ *              the throughput path for thousands of streams (what 0 picks for n > 1024): two
+ *              kernels, one wavefront per stream each -- a scan kernel (block headers, tables,
+ *              speculative Huffman scan; its decoded symbols go to a token workspace in HBM) and
+ *              an LZ77 kernel (replays the tokens, resolves matches, writes the output) -- both
+ *              at 3 wavefronts per SIMD instead of 2.  Needs device workspace
+ *              (debig_hip_inflate_batch_ws; debig_hip_inflate_batch / _ex use a cached internal
+ *              one of DEBIG_WORKSPACE_MB MiB, default 1024); a stream that does not fit its share
+ *              is decoded by the one-kernel path in the same call. */
+#define DEBIG_WAVES_SPLIT 0x10u
 int debig_hip_inflate_batch_ex(const void *d_in, void *d_out, const debig_stream *d_streams,
                                debig_result *d_results, uint32_t n, uint32_t waves_per_stream,
                                void *hip_stream);
+
+/* Same with caller-owned workspace for DEBIG_WAVES_SPLIT (no allocation inside the call: safe to
+ * capture into a hipGraph).  debig_hip_inflate_workspace_bytes() is the size that lets ordinary
+ * data through the scan/LZ77 pair (about 9 x the compressed bytes of the largest group of 16384
+ * streams + 24 KiB per stream); less is legal and only sends more streams down the one-kernel
+ * path.  d_workspace = NULL: the internal cached workspace.  The workspace holds no state between
+ * calls. */
+uint64_t debig_hip_inflate_workspace_bytes(uint64_t total_in_bytes, uint32_t n);
+int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream *d_streams,
+                               debig_result *d_results, uint32_t n, uint32_t waves_per_stream,
+                               void *d_workspace, uint64_t workspace_bytes, void *hip_stream);
 
 /* One image for the de-filter kernel: the inflated scanline stream (filter byte
  * + w*bpp bytes per row) -> 4-channel RGBA. */

@@ -35,7 +35,14 @@ def load_emu(asan=False):
     L.emu_inflate_mw_batch.restype = C.c_int
     L.emu_inflate_mw_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                        C.c_uint32]
+    L.emu_inflate_split_batch.restype = C.c_int
+    L.emu_inflate_split_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
+                                          C.POINTER(C.c_uint32)]
     return L
+
+
+SPLIT = 0x10  # nw code of the scan / LZ77 kernel pair (include/debig_hip.h: DEBIG_WAVES_SPLIT)
+last_split_retried = 0  # streams the pair handed to the one-kernel path in the last SPLIT call
 
 
 def layout_batch(raws, caps, in_misalign=0, out_misalign=0, p2=None, flags=0):
@@ -68,7 +75,7 @@ def layout_batch(raws, caps, in_misalign=0, out_misalign=0, p2=None, flags=0):
     return in_arena, out_arena, streams, results, offs
 
 
-def emu_inflate(L, raws, caps, grid=0, nw=1, classes=None, **kw):
+def emu_inflate(L, raws, caps, grid=0, nw=1, classes=None, ws_bytes=None, **kw):
     """nw = 1: debig_inflate_kernel; nw = 2 / 4: debig_inflate_mw_kernel<nw> (one stream per
     workgroup of nw wavefronts).  classes = [(nw, cls), ...]: one launch per entry, each
     restricted to a stream class (1 small, 2 large), like the shim's mixed-width mode."""
@@ -78,6 +85,14 @@ def emu_inflate(L, raws, caps, grid=0, nw=1, classes=None, **kw):
         for w, cls in classes:
             rc |= L.emu_inflate_batch_cls(in_arena.ctypes.data, out_arena.ctypes.data, streams, results,
                                           len(raws), grid, w, cls)
+    elif nw == SPLIT:
+        global last_split_retried
+        if ws_bytes is None:
+            ws_bytes = len(raws) * (32 + 24576) + 9 * sum(len(r) for r in raws)
+        nr = C.c_uint32(0)
+        rc = L.emu_inflate_split_batch(in_arena.ctypes.data, out_arena.ctypes.data, streams, results, len(raws),
+                                       ws_bytes, C.byref(nr))
+        last_split_retried = nr.value
     elif nw == 1:
         rc = L.emu_inflate_batch(in_arena.ctypes.data, out_arena.ctypes.data, streams, results, len(raws), grid)
     else:

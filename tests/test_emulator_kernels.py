@@ -26,10 +26,10 @@ def emu():
 
 
 # wavefronts per stream: 1 = debig_inflate_kernel, 2 / 4 = debig_inflate_mw_kernel<NW>
-@pytest.mark.parametrize("nw", [1, 2, 4])
+@pytest.mark.parametrize("nw", [1, 2, 4, eb.SPLIT])
 def test_known_answers_and_corpus(emu, nw):
     items = json.load(open(os.path.join(GOLD, "kat.json")))
-    items += json.load(open(os.path.join(GOLD, "corpus_zlib.json")))[:80 if nw == 1 else 40]
+    items += json.load(open(os.path.join(GOLD, "corpus_zlib.json")))[:80 if nw in (1, eb.SPLIT) else 40]
     raws = [bytes.fromhex(k["raw_hex"]) for k in items]
     caps = [k["recipient_size"] for k in items]
     outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, in_misalign=3, out_misalign=5)
@@ -44,10 +44,10 @@ def test_known_answers_and_corpus(emu, nw):
         assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
 
 
-@pytest.mark.parametrize("nw", [1, 4])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT])
 def test_corrupt_corpus_reference_made(emu, nw):
     """tests/golden/corpus_corrupt.json: damaged streams with the REFERENCE's own answers (build B)"""
-    items = json.load(open(os.path.join(GOLD, "corpus_corrupt.json")))[:: 1 if nw == 1 else 3]
+    items = json.load(open(os.path.join(GOLD, "corpus_corrupt.json")))[:: 1 if nw in (1, eb.SPLIT) else 3]
     raws = [bytes.fromhex(k["raw_hex"]) for k in items]
     caps = [k["recipient_size"] for k in items]
     outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, out_misalign=1)
@@ -57,12 +57,15 @@ def test_corrupt_corpus_reference_made(emu, nw):
         assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
 
 
+@pytest.mark.parametrize("nw", [1, eb.SPLIT])
 @pytest.mark.parametrize("kind", ["stored", "fixed", "dynamic"])
-def test_cfg2_streams(emu, oracle, kind):
+def test_cfg2_streams(emu, oracle, kind, nw):
     pairs = workload.make_streams(kind, 3, 65536)
     raws = [p[0] for p in pairs]
     caps = [max(65537, len(r)) for r in raws]
-    outs, _, _ = eb.emu_inflate(emu, raws, caps)
+    outs, _, _ = eb.emu_inflate(emu, raws, caps, nw=nw)
+    if nw == eb.SPLIT:
+        assert eb.last_split_retried == 0  # the scan / LZ77 pair itself decoded them
     for (good, final, out, r), (raw, plain) in zip(outs, pairs):
         assert (good, final) == (1, 65536) and out == plain.tobytes()
         if kind != "stored":
@@ -101,7 +104,7 @@ def test_multi_wavefront_kernel_crosses_windows_and_tiles(emu):
     assert r.n_windows >= 2
 
 
-@pytest.mark.parametrize("nw", [1, 4])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT])
 def test_end_position_and_no_gates_flag(emu, nw):
     """debig_result.in_end_bits (where decoding stopped) and DEBIG_STREAM_NO_REF_GATES: what a
     container with several members needs (debig_gunzip_batch).  A raw stream followed by other
@@ -155,7 +158,7 @@ def _tiny_block_streams(seed, count, max_len):
     return raws, caps
 
 
-@pytest.mark.parametrize("nw", [1, 4])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT])
 def test_streams_of_tiny_blocks_take_the_probe_path(emu, oracle, nw):
     raws, caps = _tiny_block_streams(31 + nw, 12 if nw == 1 else 6, 1500)
     outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, in_misalign=5, out_misalign=11)
@@ -187,7 +190,7 @@ def test_mixed_width_launches_partition_the_batch(emu, oracle):
     assert [r.final_set for _, _, _, r in only_large] == [it % 2 for it in range(10)]
 
 
-@pytest.mark.parametrize("nw", [1, 4])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT])
 def test_corrupt_streams_agree_with_oracle(emu, oracle, nw):
     rng = random.Random(4)
     raws, caps = [], []
@@ -208,7 +211,7 @@ def test_corrupt_streams_agree_with_oracle(emu, oracle, nw):
         assert (good, final, out) == (eg, ef, eo)
 
 
-@pytest.mark.parametrize("nw", [1, 4])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT])
 def test_p2_aliasing_replay_matches_reference_digest(emu, nw):
     """phoebus.png: the inflate kernel with the decode_png aliasing parameters + the
     de-filter kernel reproduce the reference's (corrupted-tail) output."""
@@ -439,7 +442,7 @@ raws = [bytes.fromhex(k["raw_hex"]) for k in items]; caps = [k["recipient_size"]
 for kind in ("stored", "dynamic"):
     raw, plain = workload.make_stream(kind, 3, 5000)
     raws.append(raw); caps.append(max(5001, len(raw))); items.append({"good": 1, "final": 5000, "plain": plain.tobytes()})
-for nw in (1, 4):
+for nw in (1, 4, eb.SPLIT):
     outs, arena, offs = eb.emu_inflate(L, raws, caps, nw=nw, in_misalign=1, out_misalign=3)
     for k, (good, final, out, r) in zip(items, outs):
         assert good == k["good"] and final == k["final"], (nw, k.get("name"))
@@ -452,3 +455,33 @@ print("asan ok")
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0")
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "asan ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+def test_split_path_hands_back_what_does_not_fit_its_workspace(emu, oracle):
+    """The scan / LZ77 kernel pair (inflate_split_kernel.inc) keeps decoded symbols as token rows in a
+    workspace carved in proportion to the input sizes.  Streams that need more than their share --
+    a workspace that is simply small, streams of tiny blocks (one record + rows per block), a
+    stream whose windows hold many more symbols than bytes suggest -- must come back from the
+    one-kernel path in the same call, bit-exact, and the rest must not be disturbed."""
+    pairs = workload.make_streams("dynamic", 3, 65536) + workload.make_streams("fixed", 2, 30000)
+    raws = [p[0] for p in pairs]
+    caps = [len(p[1]) + 1 for p in pairs]
+    tiny_raws, tiny_caps = _tiny_block_streams(77, 3, 1500)
+    raws += tiny_raws
+    caps += tiny_caps
+    # all literals with a 1-bit and a 2-bit code: 5+ symbols per input byte
+    dense = bytes(random.Random(5).choice(b"aaaaab") for _ in range(40000))
+    c = zlib.compressobj(9, zlib.DEFLATED, -15, 9, zlib.Z_HUFFMAN_ONLY)
+    raws.append(c.compress(dense) + c.flush())
+    caps.append(len(dense) + 1)
+    want = [oracle.inflate(r, c) for r, c in zip(raws, caps)]
+    seen = set()
+    for ws in (None, 9 * sum(len(r) for r in raws) // 6, 40 * 1024, len(raws) * 1024 + 4096):
+        outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=eb.SPLIT, ws_bytes=ws, out_misalign=3)
+        seen.add(eb.last_split_retried)
+        for (good, final, out, r), w in zip(outs, want):
+            assert (good, final, out) == w
+        for (io, oo), cap in zip(offs, caps):
+            assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
+    assert 0 not in seen or len(seen) > 1  # the small workspaces really sent streams back
+    assert max(seen) >= len(raws) - 1

@@ -48,7 +48,8 @@ def _payload(rng, n, kind):
 
 # wavefronts per stream: debig_inflate_kernel, debig_inflate_mw_kernel<2>, <4>, <8>, and the two
 # mixed modes (large streams 4-wide beside small ones 1- / 2-wide, include/debig_hip.h)
-WIDTHS = (1, 2, 4, 8, 0x41, 0x42)
+# 0x10 = DEBIG_WAVES_SPLIT: the scan + LZ77 kernel pair (what the library picks for n > 1024)
+WIDTHS = (1, 2, 4, 8, 0x41, 0x42, 0x10)
 
 
 def _check(oracle, gpu_device, raws, caps, widths=WIDTHS, **kw):

@@ -5,6 +5,7 @@
 #include "../../include/debig_hip.h"
 #include "../../debigulator_amd/csrc/inflate_kernel.inc"
 #include "../../debigulator_amd/csrc/inflate_mw_kernel.inc"
+#include "../../debigulator_amd/csrc/inflate_split_kernel.inc"
 #include "../../debigulator_amd/csrc/png_kernel.inc"
 #include "../../debigulator_amd/csrc/checksum_kernel.inc"
 
@@ -56,6 +57,44 @@ extern "C" int emu_inflate_batch_cls(const void *in, void *out, const debig_stre
         EMU_LAUNCH(debig_inflate_mw_kernel<8>, grid, 512, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft, cls);
     else
         return -1;
+    return 0;
+}
+
+/* the scan / LZ77 kernel pair (inflate_split_kernel.inc) with a workspace of ws_bytes, and the
+ * one-kernel path for the streams the pair hands back; *n_retried = how many those were */
+extern "C" int emu_inflate_split_batch(const void *in, void *out, const debig_stream *streams, debig_result *results,
+                                       uint32_t n, uint64_t ws_bytes, uint32_t *n_retried)
+{
+    static uint32_t *ft = nullptr;
+    if (!ft) {
+        ft = (uint32_t *)calloc(1, sizeof(CodeTabsT<TabCfg<1>::PBL>));
+        EMU_LAUNCH(debig_fixed_tables_kernel<1>, 1, 64, ft);
+    }
+    static uint32_t *fts = nullptr;
+    if (!fts) {
+        fts = (uint32_t *)calloc(1, sizeof(CodeTabsT<TabCfg<1>::PBL, uint16_t>));
+        EMU_LAUNCH(debig_scan_fixed_tables_kernel, 1, 64, fts);
+    }
+    const uint64_t slots_bytes = ((uint64_t)n * sizeof(debig_ws_slot) + 255) / 256 * 256;
+    if (ws_bytes < slots_bytes + (uint64_t)n * 1024u) return -1;
+    uint8_t *ws = (uint8_t *)malloc(ws_bytes);
+    memset(ws, 0xEE, ws_bytes); /* poison: nothing may be read before it is written */
+    const uint64_t rest = ws_bytes - slots_bytes;
+    const uint64_t total_recs = rest / 16u / sizeof(debig_ws_rec);
+    const uint64_t recs_bytes = (total_recs * sizeof(debig_ws_rec) + 255) / 256 * 256;
+    const uint64_t total_rows = (rest - recs_bytes) / 256u;
+    debig_ws_slot *slots = (debig_ws_slot *)ws;
+    debig_ws_rec *recs = (debig_ws_rec *)(ws + slots_bytes);
+    uint32_t *rows = (uint32_t *)(ws + slots_bytes + recs_bytes);
+    EMU_LAUNCH(debig_split_plan_kernel, 1, 1024, streams, n, slots, total_rows, total_recs);
+    EMU_LAUNCH(debig_scan_kernel, n, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows);
+    EMU_LAUNCH(debig_lz_kernel, n, 64, (uint8_t *)out, streams, results, n, (const debig_ws_slot *)slots,
+               (const debig_ws_rec *)recs, (const uint32_t *)rows);
+    uint32_t retried = 0;
+    for (uint32_t i = 0; i < n; i++) retried += results[i].status == DEBIG_E_RETRY;
+    if (n_retried) *n_retried = retried;
+    EMU_LAUNCH(debig_inflate_kernel, n, 64, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft, DEBIG_CLASS_RETRY);
+    free(ws);
     return 0;
 }
 
