@@ -156,7 +156,7 @@ static int launch_split_group(hipStream_t s, const void *d_in, void *d_out, cons
     uint32_t *rows = (uint32_t *)((uint8_t *)ws + slots_bytes + recs_bytes);
     hipLaunchKernelGGL(debig_split_plan_kernel, dim3(1), dim3(1024), 0, s, d_streams, n, slots, total_rows, total_recs);
     hipLaunchKernelGGL(debig_scan_kernel, dim3(n), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, n,
-                       tabs->scan, slots, recs, rows);
+                       tabs->scan, slots, recs, rows, d_results);
     hipLaunchKernelGGL(debig_lz_kernel, dim3(n), dim3(64), 0, s, (uint8_t *)d_out, d_streams, d_results, n,
                        (const debig_ws_slot *)slots, (const debig_ws_rec *)recs, (const uint32_t *)rows);
     hipLaunchKernelGGL(debig_inflate_kernel, dim3(n), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams,
