@@ -410,8 +410,12 @@ def main():
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_step": c + d,
                     "avg_step_ms": ms, "decompressed_GBps": d / ms / 1e6, "launches_per_step": launches}
 
-        lps = getattr(batch, "launches_per_step", 1)
-        rl = roof(c_bytes, d_bytes, step_ms, "the step's inflate launch(es) on rank 0 (whole batch)", lps)
+        split = len(res) > 1024  # include/debig_hip.h: what the library picks from the batch size
+        what = ("one step = debig_split_plan_kernel + debig_scan_kernel + debig_lz_kernel (+ debig_inflate_kernel for "
+                "streams handed back: none here), whole batch on rank 0" if split else
+                "one step = one debig_inflate(_mw)_kernel launch, whole batch on rank 0")
+        lps = 4 if split else 1
+        rl = roof(c_bytes, d_bytes, step_ms, what, lps)
         if not cfg5:
             tr, src = pmc_traffic(digest, args.streams / STREAMS_PER_KIND)
             rl["traffic"] = tr
@@ -457,8 +461,8 @@ def main():
             r = sub.results()
             assert (r["good"] == 1).all()
             name = "roofline_huffman" if kind == "fixed" else "roofline_stored"
-            line[name] = roof(cb, db, ms, f"{kind} streams launched alone ({len(r)} x 64 KiB)",
-                              getattr(sub, "launches_per_step", 1))
+            line[name] = roof(cb, db, ms, f"{kind} streams launched alone ({len(r)} x 64 KiB), same kernels",
+                              4 if len(r) > 1024 else 1)
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)

@@ -1,27 +1,56 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 --pmc CSVs made by tools/pmc_traffic.sh (bench.py: every launch of
-debig_inflate_kernel is the same batch) and write profiles/pmc_traffic.json for bench.py."""
-import csv, glob, json, os
-out = {}
+"""Summarise the rocprofv3 --pmc CSVs made by tools/pmc_traffic.sh (bench.py: every step is the
+same batch) and write profiles/pmc_traffic.json for bench.py.  A step is several launches since
+round 2 (workspace plan, scan kernel, LZ77 kernel, the one-kernel path for handed-back streams):
+the bytes of all debig_* kernels between two plan launches are one step."""
+import csv, glob, hashlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out, per_kernel = {}, {}
 for name in ("fetch", "write"):
     files = glob.glob(f"gpurun_out/pmc_traffic_{name}/**/*counter_collection.csv", recursive=True)
     if not files:
         continue
     f = max(files, key=os.path.getmtime)
-    rows = [r for r in csv.DictReader(open(f)) if "debig_inflate_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "debig_" in r["Kernel_Name"] and "tables" not in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    vals = [float(r["Counter_Value"]) for r in rows]
-    out[name] = (sum(vals[-3:]) / 3, rows[0]["Counter_Name"], len(vals))
+    # steps: split at every plan kernel (or every one-kernel launch when the plan kernel is absent)
+    steps, cur = [], []
+    marker = "debig_split_plan_kernel" if any("debig_split_plan_kernel" in r["Kernel_Name"] for r in rows) else "debig_inflate_kernel"
+    for r in rows:
+        if marker in r["Kernel_Name"] and cur:
+            steps.append(cur)
+            cur = []
+        cur.append(r)
+    if cur:
+        steps.append(cur)
+    # the bench also launches each stream kind alone (smaller grids): keep the whole-batch steps
+    big = max(max(int(r["Grid_Size"]) for r in st) for st in steps)
+    steps = [st for st in steps if max(int(r["Grid_Size"]) for r in st) == big]
+    last = steps[-3:]
+    out[name] = (sum(sum(float(r["Counter_Value"]) for r in st) for st in last) / len(last), rows[0]["Counter_Name"], len(steps))
+    for r in last[-1]:
+        k = r["Kernel_Name"].split("(")[0]
+        per_kernel.setdefault(k, {})[name] = per_kernel.get(k, {}).get(name, 0.0) + float(r["Counter_Value"])
 for name, (v, cn, n) in out.items():
-    print(f"{cn}: {v:.1f} KB per launch (raw counter, mean of the last 3 of {n} launches)")
+    print(f"{cn}: {v:.1f} KB per step (raw counter, mean of the last 3 of {n} steps)")
+for k, d in per_kernel.items():
+    print(f"  {k:28s} FETCH_SIZE {d.get('fetch', 0):12.1f} KB raw   WRITE_SIZE {d.get('write', 0):12.1f} KB")
 if "fetch" in out and "write" in out:
     f, w = out["fetch"][0], out["write"][0]
-    b = (2 * f + w) * 1024
-    # gfx950: FETCH_SIZE reports 1/2 of a wide coalesced read stream (MI355X_MICROARCH.md, HBM)
-    print(f"HBM traffic ~= 2*FETCH + WRITE = {b/1e6:.1f} MB per launch (FETCH {f*1024/1e6:.1f} MB raw, WRITE {w*1024/1e6:.1f} MB)")
+    # gfx950: FETCH_SIZE reports 1/2 of a WIDE coalesced read stream (MI355X_MICROARCH.md, HBM): that is
+    # the scan kernel (16 B/lane input staging, stored-block copies) and the one-kernel path; the LZ77
+    # kernel reads 4 B/lane token rows and 16-byte history gathers, for which the counter is taken as is
+    wide = sum(d.get("fetch", 0.0) for k, d in per_kernel.items() if "lz_kernel" not in k)
+    b = (f + wide + w) * 1024
+    print(f"HBM traffic ~= FETCH (x2 for the wide-read kernels) + WRITE = {b/1e6:.1f} MB per step "
+          f"(FETCH {f*1024/1e6:.1f} MB raw, of it {wide*1024/1e6:.1f} MB wide reads; WRITE {w*1024/1e6:.1f} MB)")
+    from bench import kernel_sources_digest
     json.dump({"bytes_per_launch": b, "fetch_size_kb_raw": f, "write_size_kb": w,
+               "per_kernel_kb_raw": per_kernel, "kernel_sources_sha256": kernel_sources_digest(),
+               "source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py (tools/pmc_traffic.sh)",
                "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py "
-                      "(tools/pmc_traffic.sh); bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB: gfx950 reports half of a wide "
-                      "coalesced read stream (MI355X_MICROARCH.md, HBM); the LZ77 history reads are 4-byte L2 loads, for "
-                      "which the factor 2 is uncalibrated (upper estimate)"},
+                      "(tools/pmc_traffic.sh), summed over the kernels of one whole-batch step; FETCH_SIZE doubled for the "
+                      "kernels whose reads are wide coalesced streams (gfx950 reports half of those: MI355X_MICROARCH.md, "
+                      "HBM), taken as is for the LZ77 kernel (4 B/lane token rows, 16-byte history gathers: uncalibrated)"},
               open("profiles/pmc_traffic.json", "w"), indent=1)
