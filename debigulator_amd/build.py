@@ -41,7 +41,7 @@ def build(force=False, verbose=False, extra_defs=(), out=None):
     defs = ["-D" + d for d in extra_defs]
     for c in sorted(glob.glob(os.path.join(CSRC, "host", "*.c"))):
         o = os.path.join(odir, os.path.basename(c) + ".o")
-        cmd = ["gcc", "-O2", "-fPIC", "-std=c11", "-Wall", "-Wextra", "-fvisibility=hidden"] + inc + ["-c", c, "-o", o]
+        cmd = ["gcc", "-O2", "-fPIC", "-std=c11", "-D_GNU_SOURCE", "-pthread", "-Wall", "-Wextra", "-fvisibility=hidden"] + inc + ["-c", c, "-o", o]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -54,7 +54,7 @@ def build(force=False, verbose=False, extra_defs=(), out=None):
     subprocess.check_call(cmd)
     objs.append(o)
     # -Bsymbolic: our internal calls must never bind to zlib's `inflate`
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", target] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", target] + objs + ["-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -318,6 +318,14 @@ int debig_hip_memset(void *d, int v, uint64_t bytes, void *s)
     return (int)hipMemsetAsync(d, v, bytes, (hipStream_t)s);
 }
 int debig_hip_stream_sync(void *s) { return (int)hipStreamSynchronize((hipStream_t)s); }
+void *debig_hip_host_alloc(uint64_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void debig_hip_host_free(void *p) { (void)hipHostFree(p); }
+int debig_hip_event_sync(void *ev) { return (int)hipEventSynchronize((hipEvent_t)ev); }
 const char *debig_hip_error_string(int err) { return hipGetErrorString((hipError_t)err); }
 void *debig_hip_event_create(void)
 {

@@ -1,4 +1,7 @@
 #include "debig_ctx.h"
+#include <pthread.h>
+#include <string.h>
+#include <unistd.h>
 
 static debig_ctx g_ctx[DEBIG_MAX_THREADS];
 
@@ -41,6 +44,147 @@ void debig_ctx_release(uint32_t thread_id)
     buf_free(&c->crcs);
     buf_free(&c->copies);
     buf_free(&c->ws);
+    if (c->pin_in.ptr) debig_hip_host_free(c->pin_in.ptr);
+    if (c->pin_out.ptr) debig_hip_host_free(c->pin_out.ptr);
+    c->pin_in.ptr = c->pin_out.ptr = NULL;
+    c->pin_in.cap = c->pin_out.cap = 0;
+    for (int k = 0; k < DEBIG_STAGE_CHUNKS; k++) {
+        if (c->ev[k]) debig_hip_event_destroy(c->ev[k]);
+        c->ev[k] = NULL;
+    }
+}
+
+/* ---- page-locked staging */
+static int pin_reserve(debig_devbuf *b, uint64_t bytes)
+{
+    if (b->cap >= bytes && b->ptr) return 0;
+    if (b->ptr) debig_hip_host_free(b->ptr);
+    uint64_t cap = bytes + bytes / 4 + 4096;
+    b->ptr = debig_hip_host_alloc(cap);
+    b->cap = b->ptr ? cap : 0;
+    return b->ptr ? 0 : 2;
+}
+
+#define DEBIG_STAGE_THREADS 12
+typedef struct copy_job {
+    uint8_t *base;              /* pinned arena */
+    uint8_t *const *dsts;       /* download: destinations */
+    const uint8_t *const *srcs; /* upload: sources */
+    const uint64_t *sizes, *offs;
+    uint32_t lo, hi;            /* streams [lo, hi) */
+    uint64_t arena_lo, arena_hi; /* download: only streams whose last byte lies in [arena_lo, arena_hi) */
+} copy_job;
+
+static void *copy_worker(void *arg)
+{
+    const copy_job *j = (const copy_job *)arg;
+    for (uint32_t i = j->lo; i < j->hi; i++) {
+        if (!j->sizes[i]) continue;
+        if (j->srcs) {
+            if (j->srcs[i]) memcpy(j->base + j->offs[i], j->srcs[i], (size_t)j->sizes[i]);
+        } else if (j->dsts[i]) {
+            const uint64_t last = j->offs[i] + j->sizes[i] - 1u; /* the piece its LAST byte arrives in */
+            if (last >= j->arena_lo && last < j->arena_hi) memcpy(j->dsts[i], j->base + j->offs[i], (size_t)j->sizes[i]);
+        }
+    }
+    return NULL;
+}
+
+static uint32_t stage_threads(uint64_t bytes)
+{
+    long nc = sysconf(_SC_NPROCESSORS_ONLN);
+    uint32_t t = nc > DEBIG_STAGE_THREADS ? (uint32_t)DEBIG_STAGE_THREADS : (nc < 1 ? 1u : (uint32_t)nc);
+    if (bytes < (1u << 20)) t = 1; /* not worth a thread */
+    return t;
+}
+
+/* run the job over streams [0, n) on several threads, split by stream count */
+static void run_copy(copy_job proto, uint32_t n, uint64_t bytes)
+{
+    const uint32_t nt = stage_threads(bytes);
+    pthread_t th[DEBIG_STAGE_THREADS];
+    copy_job jobs[DEBIG_STAGE_THREADS];
+    uint32_t started = 0;
+    for (uint32_t t = 0; t < nt; t++) {
+        jobs[t] = proto;
+        jobs[t].lo = (uint32_t)((uint64_t)n * t / nt);
+        jobs[t].hi = (uint32_t)((uint64_t)n * (t + 1) / nt);
+        if (t + 1 == nt || pthread_create(&th[t], NULL, copy_worker, &jobs[t]) != 0) {
+            copy_worker(&jobs[t]); /* the calling thread takes the last share (and any that failed to start) */
+            continue;
+        }
+        started |= 1u << t;
+    }
+    for (uint32_t t = 0; t < nt; t++)
+        if (started & (1u << t)) pthread_join(th[t], NULL);
+}
+
+int debig_upload_packed(debig_ctx *c, void *d_arena, const uint8_t *const *srcs, const uint64_t *sizes,
+                        const uint64_t *offs, uint32_t n, uint64_t total)
+{
+    if (total == 0 || n == 0) return 0;
+    /* the previous call's H2D out of this arena has completed: every batch call synchronises */
+    if (pin_reserve(&c->pin_in, total)) return 2;
+    copy_job j;
+    memset(&j, 0, sizeof j);
+    j.base = (uint8_t *)c->pin_in.ptr;
+    j.srcs = srcs;
+    j.sizes = sizes;
+    j.offs = offs;
+    uint64_t bytes = 0;
+    int ascending = 1;
+    for (uint32_t i = 0; i < n; i++) {
+        bytes += sizes[i];
+        if (i && offs[i] < offs[i - 1]) ascending = 0;
+    }
+    /* two halves (callers lay streams out in ascending order): the first half is on the wire while
+     * the threads pack the second */
+    uint32_t m = 0;
+    while (ascending && m < n && offs[m] < total / 2) m++;
+    if (!ascending || m == 0 || m == n || bytes < (8u << 20)) {
+        run_copy(j, n, bytes);
+        return debig_hip_memcpy_h2d(d_arena, c->pin_in.ptr, total, NULL);
+    }
+    copy_job a = j, b = j;
+    b.srcs = srcs + m; b.sizes = sizes + m; b.offs = offs + m;
+    run_copy(a, m, bytes / 2);
+    int rc = debig_hip_memcpy_h2d(d_arena, c->pin_in.ptr, offs[m], NULL);
+    run_copy(b, n - m, bytes / 2);
+    if (!rc) rc = debig_hip_memcpy_h2d((uint8_t *)d_arena + offs[m], (uint8_t *)c->pin_in.ptr + offs[m], total - offs[m], NULL);
+    return rc;
+}
+
+int debig_download_unpack(debig_ctx *c, const void *d_arena, uint8_t *const *dsts, const uint64_t *sizes,
+                          const uint64_t *offs, uint32_t n, uint64_t total)
+{
+    if (total == 0 || n == 0) return debig_hip_stream_sync(NULL);
+    if (pin_reserve(&c->pin_out, total)) return 2;
+    for (int k = 0; k < DEBIG_STAGE_CHUNKS; k++)
+        if (!c->ev[k] && !(c->ev[k] = debig_hip_event_create())) return 2;
+    uint64_t bytes = 0;
+    for (uint32_t i = 0; i < n; i++) bytes += sizes[i];
+    /* pieces of equal size; a stream is unpacked with the piece that holds its LAST byte (the
+     * copies are issued in order, so everything before it has landed as well) */
+    const uint64_t step = (total + DEBIG_STAGE_CHUNKS - 1) / DEBIG_STAGE_CHUNKS;
+    int rc = 0;
+    for (int k = 0; k < DEBIG_STAGE_CHUNKS && !rc; k++) {
+        const uint64_t lo = step * (uint64_t)k, hi = lo + step < total ? lo + step : total;
+        if (lo < hi) rc = debig_hip_memcpy_d2h((uint8_t *)c->pin_out.ptr + lo, (const uint8_t *)d_arena + lo, hi - lo, NULL);
+        if (!rc) rc = debig_hip_event_record(c->ev[k], NULL);
+    }
+    copy_job j;
+    memset(&j, 0, sizeof j);
+    j.base = (uint8_t *)c->pin_out.ptr;
+    j.dsts = dsts;
+    j.sizes = sizes;
+    j.offs = offs;
+    for (int k = 0; k < DEBIG_STAGE_CHUNKS && !rc; k++) {
+        rc = debig_hip_event_sync(c->ev[k]);
+        j.arena_lo = step * (uint64_t)k;
+        j.arena_hi = j.arena_lo + step;
+        if (!rc) run_copy(j, n, bytes / DEBIG_STAGE_CHUNKS);
+    }
+    return rc;
 }
 
 int debig_launch_inflate_planned(debig_ctx *c, const void *d_in_arena, const debig_stream *desc,

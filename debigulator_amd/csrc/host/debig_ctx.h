@@ -9,6 +9,7 @@
 #define DEBIG_MAX_THREADS 10 /* reference: INFLATE_MAX_THREADS / PNG_DECODER_MAX_THREADS */
 #define DEBIG_API __attribute__((visibility("default")))
 
+#define DEBIG_STAGE_CHUNKS 4
 typedef struct debig_devbuf {
     void *ptr;
     uint64_t cap;
@@ -18,6 +19,8 @@ typedef struct debig_ctx {
     debig_devbuf in, out, desc, res, rgba, img, imgres;
     debig_devbuf files, spans, crcs, copies; /* PNG: whole files, chunk spans, their CRCs, IDAT gather list */
     debig_devbuf ws; /* token workspace of the scan / LZ77 kernel pair (DEBIG_WAVES_SPLIT) */
+    debig_devbuf pin_in, pin_out; /* page-locked staging arenas (host memory) */
+    void *ev[DEBIG_STAGE_CHUNKS]; /* download pipeline events */
 } debig_ctx;
 
 debig_ctx *debig_ctx_get(uint32_t thread_id);
@@ -26,6 +29,20 @@ int debig_devbuf_reserve(debig_devbuf *b, uint64_t bytes);
 void debig_ctx_release(uint32_t thread_id);
 
 static inline uint64_t debig_align16(uint64_t x) { return (x + 15u) & ~(uint64_t)15u; }
+
+/* Host buffers <-> device arena through page-locked staging, the way PCIe likes it (one big
+ * transfer instead of one small pageable copy per stream: 11 us each, profiles/r01_host_api.txt).
+ *   debig_upload_packed    srcs[i] (sizes[i] bytes, may be NULL / 0) -> d_arena + offs[i]: packed
+ *                          into the pinned arena by several host threads, then ONE H2D of
+ *                          [0, total).  Asynchronous on the default stream.
+ *   debig_download_unpack  d_arena + offs[i] -> dsts[i] (sizes[i] bytes): the arena comes down in
+ *                          DEBIG_STAGE_CHUNKS pieces; while piece k+1 is on the wire the host threads
+ *                          copy piece k out to the callers' buffers.  Synchronises.
+ * Both return 0 or an error code. */
+int debig_upload_packed(debig_ctx *c, void *d_arena, const uint8_t *const *srcs, const uint64_t *sizes,
+                        const uint64_t *offs, uint32_t n, uint64_t total);
+int debig_download_unpack(debig_ctx *c, const void *d_arena, uint8_t *const *dsts, const uint64_t *sizes,
+                          const uint64_t *offs, uint32_t n, uint64_t total);
 
 /* waves_per_stream for debig_hip_inflate_batch_ex from what the host knows about the batch
  * (the shim itself only sees n: descriptors live in device memory).  Few streams: several

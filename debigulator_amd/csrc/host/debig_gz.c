@@ -227,9 +227,19 @@ DEBIG_API int debig_gunzip_batch(const uint8_t *const *inputs, const uint64_t *i
     }
     if ((rc = debig_devbuf_reserve(&c->files, in_total + 64)) || (rc = debig_devbuf_reserve(&c->out, out_total + 64)))
         goto done;
-    for (uint32_t i = 0; i < n && !rc; i++)
-        if (F[i].active && input_sizes[i])
-            rc = debig_hip_memcpy_h2d((uint8_t *)c->files.ptr + F[i].dev_in, inputs[i], input_sizes[i], NULL);
+    {
+        /* whole files up in one transfer through the page-locked arena */
+        uint64_t *up_sizes = (uint64_t *)calloc(n, sizeof(uint64_t));
+        uint64_t *up_offs = (uint64_t *)calloc(n, sizeof(uint64_t));
+        if (!up_sizes || !up_offs) { free(up_sizes); free(up_offs); rc = 2; goto done; }
+        for (uint32_t i = 0; i < n; i++) {
+            up_sizes[i] = F[i].active ? input_sizes[i] : 0;
+            up_offs[i] = F[i].dev_in;
+        }
+        rc = debig_upload_packed(c, c->files.ptr, inputs, up_sizes, up_offs, n, in_total);
+        free(up_sizes);
+        free(up_offs);
+    }
     if (rc) goto done;
 
     for (;;) {
@@ -352,13 +362,23 @@ DEBIG_API int debig_gunzip_batch(const uint8_t *const *inputs, const uint64_t *i
     }
     /* ---- results back to the host */
     rc = 0;
-    for (uint32_t i = 0; i < n && !rc; i++) {
-        status[i] = F[i].status;
-        if (n_members) n_members[i] = F[i].members;
-        out_sizes[i] = F[i].used;
-        if (F[i].used && outs[i]) rc = debig_hip_memcpy_d2h(outs[i], (uint8_t *)c->out.ptr + F[i].dev_out, F[i].used, NULL);
+    {
+        uint64_t *dn_sizes = (uint64_t *)calloc(n, sizeof(uint64_t));
+        uint64_t *dn_offs = (uint64_t *)calloc(n, sizeof(uint64_t));
+        if (!dn_sizes || !dn_offs) { free(dn_sizes); free(dn_offs); rc = 2; goto done; }
+        uint64_t last_end = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            status[i] = F[i].status;
+            if (n_members) n_members[i] = F[i].members;
+            out_sizes[i] = F[i].used;
+            dn_sizes[i] = outs[i] ? F[i].used : 0;
+            dn_offs[i] = F[i].dev_out;
+            if (dn_sizes[i] && dn_offs[i] + dn_sizes[i] > last_end) last_end = dn_offs[i] + dn_sizes[i];
+        }
+        rc = debig_download_unpack(c, c->out.ptr, outs, dn_sizes, dn_offs, n, last_end);
+        free(dn_sizes);
+        free(dn_offs);
     }
-    if (!rc) rc = debig_hip_stream_sync(NULL);
 done:
     free(F);
     free(items);

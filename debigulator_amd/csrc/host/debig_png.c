@@ -322,9 +322,16 @@ DEBIG_API int debig_decode_png_batch(const uint8_t *const *inputs, const uint64_
         goto done_bulk;
     {
         uint32_t ci = 0, pi = 0;
+        {
+            /* whole files up in one transfer through the page-locked arena */
+            uint64_t *up_sizes = (uint64_t *)calloc(n, sizeof(uint64_t));
+            if (!up_sizes) { rc = 2; goto done_bulk; }
+            for (uint32_t i = 0; i < n; i++) up_sizes[i] = P[i].ok ? input_sizes[i] : 0;
+            rc = debig_upload_packed(c, c->files.ptr, inputs, up_sizes, file_off, n, files_total);
+            free(up_sizes);
+        }
         for (uint32_t i = 0; i < n && !rc; i++) {
             if (!P[i].ok) continue;
-            rc = debig_hip_memcpy_h2d((uint8_t *)c->files.ptr + file_off[i], inputs[i], input_sizes[i], NULL);
             for (uint32_t k = 0; k < P[i].n_chunks; k++, ci++) {
                 spans[ci].off = file_off[i] + P[i].chunks[k].off;
                 spans[ci].len = P[i].chunks[k].len;
@@ -401,13 +408,27 @@ done_bulk:
                                               (debig_png_result *)c->imgres.ptr, nimg, NULL);
         if (!rc) rc = debig_hip_memcpy_d2h(ires, c->imgres.ptr, (uint64_t)nimg * sizeof(debig_png_result), NULL);
         if (!rc) rc = debig_hip_stream_sync(NULL);
-        for (uint32_t k = 0; k < nimg && !rc; k++) {
-            uint32_t i = map[k];
-            if (!ires[k].good) continue;
-            rc = debig_hip_memcpy_d2h(outs[i], (uint8_t *)c->rgba.ptr + img[k].rgba_off, out_sizes[i], NULL);
-            goods[i] = 1;
+        if (!rc) {
+            /* RGBA down in pieces through the page-locked arena, unpacked behind the wire */
+            uint8_t **dn_dsts = (uint8_t **)calloc(nimg, sizeof(uint8_t *));
+            uint64_t *dn_sizes = (uint64_t *)calloc(nimg, sizeof(uint64_t));
+            uint64_t *dn_offs = (uint64_t *)calloc(nimg, sizeof(uint64_t));
+            if (!dn_dsts || !dn_sizes || !dn_offs) rc = 2;
+            uint64_t last_end = 0;
+            for (uint32_t k = 0; k < nimg && !rc; k++) {
+                uint32_t i = map[k];
+                dn_offs[k] = img[k].rgba_off;
+                if (!ires[k].good) continue;
+                dn_dsts[k] = outs[i];
+                dn_sizes[k] = out_sizes[i];
+                if (dn_offs[k] + dn_sizes[k] > last_end) last_end = dn_offs[k] + dn_sizes[k];
+                goods[i] = 1;
+            }
+            if (!rc) rc = debig_download_unpack(c, c->rgba.ptr, dn_dsts, dn_sizes, dn_offs, nimg, last_end);
+            free(dn_dsts);
+            free(dn_sizes);
+            free(dn_offs);
         }
-        if (!rc) rc = debig_hip_stream_sync(NULL);
     }
     free(map);
 done:

@@ -201,11 +201,15 @@ int debig_hip_memcpy_h2d(void *d, const void *h, uint64_t bytes, void *hip_strea
 int debig_hip_memcpy_d2h(void *h, const void *d, uint64_t bytes, void *hip_stream);
 int debig_hip_memset(void *d, int v, uint64_t bytes, void *hip_stream);
 int debig_hip_stream_sync(void *hip_stream);
+/* page-locked host memory (staging arenas of the host-buffer batch calls) */
+void *debig_hip_host_alloc(uint64_t bytes);
+void debig_hip_host_free(void *p);
 const char *debig_hip_error_string(int err);
 /* kernel timing on the stream the kernels run on (hipEvent based) */
 void *debig_hip_event_create(void);
 int debig_hip_event_record(void *ev, void *hip_stream);
 float debig_hip_event_elapsed_ms(void *start, void *stop); /* synchronises on stop */
+int debig_hip_event_sync(void *ev);
 void debig_hip_event_destroy(void *ev);
 
 #ifdef __cplusplus

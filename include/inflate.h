@@ -52,6 +52,19 @@ int debig_inflate_batch(uint8_t *const *outs, const uint64_t *out_caps, uint64_t
                         const uint8_t *const *ins, const uint64_t *in_sizes, uint32_t *goods,
                         uint32_t n, const uint32_t thread_id);
 
+/* Extension: the same batch over several GPUs of one host process (streams are
+ * independent; stream i goes to GPU i mod n_devices, as BASELINE config 5 asks; no payload ever
+ * crosses GPUs, and inside one process there is no shard map to broadcast: every worker derives
+ * its share from i mod n_devices -- the RCCL broadcast of debigulator_amd/shard.py is for ranks
+ * that are separate processes).  One host thread and one device context per GPU; staging as in
+ * debig_inflate_batch.  n_devices = 0: every visible GPU.  Returns 0 or a HIP error code
+ * (hipErrorInvalidDevice when fewer GPUs are visible).
+ * debig_shard_round_robin lists the streams of one device (idx_out may be NULL): host only. */
+uint32_t debig_shard_round_robin(uint32_t n, uint32_t n_devices, uint32_t device, uint32_t *idx_out);
+int debig_inflate_batch_multi(uint8_t *const *outs, const uint64_t *out_caps, uint64_t *finals,
+                              const uint8_t *const *ins, const uint64_t *in_sizes, uint32_t *goods,
+                              uint32_t n, uint32_t n_devices);
+
 #ifdef __cplusplus
 }
 #endif

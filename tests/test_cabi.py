@@ -162,3 +162,24 @@ def test_png_probe_rejects_wrapped_dimensions_host_only(native_lib, oracle):
         tiny = _png_file(4, 4, 6, payload)
         assert probe(tiny, 64)[0] == 0
         assert oracle.decode_png(tiny, rgba_size=64)[0] == 0
+
+
+def test_multi_device_shard_partition_host_only(native_lib):
+    """debig_shard_round_robin (include/inflate.h): stream i -> GPU i mod n (BASELINE config 5); the
+    shares of all devices partition the batch.  Pure host code."""
+    import ctypes as C
+
+    f = native_lib.debig_shard_round_robin
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    for n, nd in ((0, 4), (1, 8), (7, 2), (65536, 8), (1000, 3), (5, 16)):
+        seen = []
+        for d in range(nd):
+            cnt = f(n, nd, d, None)
+            buf = (C.c_uint32 * max(cnt, 1))()
+            assert f(n, nd, d, buf) == cnt
+            got = list(buf[:cnt])
+            assert got == list(range(d, n, nd))
+            seen += got
+        assert sorted(seen) == list(range(n))
+    assert f(10, 0, 0, None) == 0 and f(10, 4, 4, None) == 0

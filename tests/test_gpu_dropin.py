@@ -5,9 +5,12 @@ import glob
 import hashlib
 import json
 import os
+import random
 
 import numpy as np
 import pytest
+
+from debigulator_amd import workload
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -318,3 +321,51 @@ def test_gunzip_batch_headers_members_and_trailers(api):
             assert members == wmem, (i, members)
     # python agrees on the multi-member file
     assert gzip.decompress(files[2]) == want[2][1]
+
+
+def test_inflate_batch_multi_one_device_and_staging(api, oracle):
+    """debig_inflate_batch_multi (include/inflate.h) with n_devices = 1 (one worker thread, its own
+    device context) and debig_inflate_batch over 3000 host-buffer streams: inputs go up in one
+    transfer through the page-locked arena, outputs come down in pieces and are unpacked by host
+    threads.  Mixed sizes, a gated stream, a failing stream, a NULL input -- vs the oracle."""
+    import ctypes as C
+
+    L = api._lib()
+    L.debig_inflate_batch_multi.restype = C.c_int
+    L.debig_inflate_batch_multi.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_uint32]
+    rng = random.Random(31)
+    raws, caps = [], []
+    for i in range(3000):
+        kind = ("fixed", "dynamic", "stored")[i % 3]
+        raw, plain = workload.make_stream(kind, 7000 + i, rng.choice([700, 5000, 20000, 65536]))
+        if i % 97 == 5:
+            raw = raw[: len(raw) // 2]  # damaged
+        raws.append(raw)
+        caps.append(max(len(plain) + 1, len(raw)) if i % 211 else 8)  # a few fail the size gate
+    want = [oracle.inflate(r, c) for r, c in zip(raws, caps)]
+    got = api.inflate_batch(raws, caps)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, i
+    # the multi-device entry point, one device
+    n = 600
+    ins = [np.frombuffer(r, dtype=np.uint8) for r in raws[:n]]
+    outs = [np.zeros(max(c, 1), dtype=np.uint8) for c in caps[:n]]
+    in_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in ins])
+    out_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in outs])
+    in_ptrs[17] = None  # NULL input: that stream is skipped, goods = 0, final untouched
+    in_sizes = (C.c_uint64 * n)(*[len(a) for a in ins])
+    capsa = (C.c_uint64 * n)(*caps[:n])
+    finals = (C.c_uint64 * n)(*([api.NOT_SET] * n))
+    goods = (C.c_uint32 * n)()
+    assert L.debig_inflate_batch_multi(out_ptrs, capsa, finals, in_ptrs, in_sizes, goods, n, 1) == 0
+    for i in range(n):
+        g, f, o = want[i]
+        if i == 17:
+            assert goods[i] == 0 and finals[i] == api.NOT_SET
+            continue
+        assert goods[i] == g, i
+        if f is None:
+            assert finals[i] == api.NOT_SET
+        else:
+            assert finals[i] == f and outs[i][:f].tobytes() == o, i
+    assert L.debig_inflate_batch_multi(out_ptrs, capsa, finals, in_ptrs, in_sizes, goods, n, 9) != 0  # no such device

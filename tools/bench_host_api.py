@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the drop-in batch call (host buffers in, host buffers out):
 debig_inflate_batch over config-2 streams, timing ONLY the C call (buffers and pointer arrays
-are prepared before).  Reported in DESIGN.md; never bench.py's `value`."""
+are prepared before; the caller's buffers are ordinary pageable memory).  Reported in DESIGN.md;
+never bench.py's `value`.   usage: bench_host_api.py [n=2048]"""
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -25,7 +26,7 @@ for kind in ("stored", "fixed", "dynamic"):
     finals = (C.c_uint64 * n)(*([NOT_SET] * n))
     goods = (C.c_uint32 * n)()
     ts = []
-    for it in range(4):
+    for it in range(6):
         t0 = time.perf_counter()
         rc = L.debig_inflate_batch(out_ptrs, caps, finals, in_ptrs, in_sizes, goods, n, 0)
         ts.append(time.perf_counter() - t0)
@@ -34,4 +35,4 @@ for kind in ("stored", "fixed", "dynamic"):
     assert outs[7][:65536].tobytes() == pairs[7][1].tobytes() and outs[n - 1][:65536].tobytes() == pairs[n - 1][1].tobytes()
     dt = min(ts[1:])
     print(f"host-buffer batch, {kind:7s}: {n} streams, {dt*1e3:8.1f} ms, {n*65536/dt/1e9:6.2f} GB/s decompressed "
-          f"(C call only: H2D + kernel + D2H)", flush=True)
+          f"(C call only: pack + H2D + kernels + D2H + unpack, best of {len(ts)-1})", flush=True)
