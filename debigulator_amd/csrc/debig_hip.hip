@@ -276,16 +276,42 @@ int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d
     return debig_hip_inflate_batch_ex(d_in, d_out, d_streams, d_results, n, 0, hip_stream);
 }
 
+// Wavefronts per image for the de-filter (png_kernel.inc): few images -> several wavefronts each
+// (bands pipelined through the workgroup), many images -> one each.  DEBIG_DEFILTER_WAVES=1|2|4|8
+// overrides (measurements).
+static uint32_t defilter_waves(uint32_t n)
+{
+    static int env_read = 0;
+    static uint32_t env_val = 0;
+    if (!env_read) {
+        const char *e = getenv("DEBIG_DEFILTER_WAVES");
+        if (e && *e) env_val = (uint32_t)strtoul(e, nullptr, 0);
+        env_read = 1;
+    }
+    if (env_val == 1 || env_val == 2 || env_val == 4 || env_val == 8) return env_val;
+    if (n <= 256u) return 8u;
+    if (n <= 512u) return 4u;
+    if (n <= 1024u) return 2u;
+    return 1u;
+}
+
 int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena,
                                  const debig_png_image *d_images, debig_png_result *d_results,
                                  uint32_t n, void *hip_stream)
 {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(debig_png_defilter_kernel, dim3(n), dim3(64), 0, (hipStream_t)hip_stream,
-                       (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images,
-                       d_results, n);
+    const uint32_t nwd = defilter_waves(n);
+    hipStream_t s = (hipStream_t)hip_stream;
+#define DEFILTER_LAUNCH(W)                                                                              \
+    hipLaunchKernelGGL(debig_png_defilter_kernel<W>, dim3(n), dim3(64 * W), 0, s, (const uint8_t *)d_streams_arena, \
+                       (uint8_t *)d_rgba_arena, d_images, d_results, n)
+    if (nwd == 8) DEFILTER_LAUNCH(8);
+    else if (nwd == 4) DEFILTER_LAUNCH(4);
+    else if (nwd == 2) DEFILTER_LAUNCH(2);
+    else DEFILTER_LAUNCH(1);
+#undef DEFILTER_LAUNCH
     // colour type 2 images that ask for the reference's exact (P3) output; a no-op otherwise
-    hipLaunchKernelGGL(debig_png_p3_kernel, dim3(n), dim3(64), 0, (hipStream_t)hip_stream,
+    hipLaunchKernelGGL(debig_png_p3_kernel, dim3(n), dim3(PNG_P3_THREADS), 0, s,
                        (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images,
                        d_results, n);
     return (int)hipGetLastError();

@@ -235,9 +235,9 @@ def test_p2_aliasing_replay_matches_reference_digest(emu, nw):
     assert hashlib.sha256(rgba.tobytes()).hexdigest() == gold["rgba_sha256"]
 
 
-def _emu_defilter(emu, stream, w, h, ct, palette=None):
-    emu.emu_png_defilter_batch.restype = C.c_int
-    emu.emu_png_defilter_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+def _emu_defilter(emu, stream, w, h, ct, palette=None, nwd=1, expect_good=1):
+    emu.emu_png_defilter_batch_w.restype = C.c_int
+    emu.emu_png_defilter_batch_w.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
     sa = np.zeros(len(stream) + 1024 + 768, dtype=np.uint8)
     sa[1:1 + len(stream)] = np.frombuffer(stream, dtype=np.uint8)  # odd offset: rows are never aligned
     pal_off = (1 + len(stream) + 15) // 16 * 16
@@ -248,8 +248,10 @@ def _emu_defilter(emu, stream, w, h, ct, palette=None):
     img[0].stream_off, img[0].rgba_off, img[0].pal_off = 1, 0, pal_off
     img[0].width, img[0].height, img[0].color_type, img[0].asserts_off = w, h, ct, 0
     res = (DebigPngResult * 1)()
-    assert emu.emu_png_defilter_batch(sa.ctypes.data, rgba.ctypes.data, img, res, 1) == 0
-    assert res[0].good == 1
+    assert emu.emu_png_defilter_batch_w(sa.ctypes.data, rgba.ctypes.data, img, res, 1, nwd) == 0
+    assert res[0].good == expect_good
+    if not expect_good:
+        return res[0].bad_row
     return rgba[: 4 * w * h]
 
 
@@ -330,6 +332,37 @@ def test_defilter_kernel_group_and_band_edges(emu, ct):
             idx = want[:, :, 0].astype(np.int64)
             exp = np.stack([pal[idx], pal[256 + idx], pal[512 + idx], np.full((h, w), 255, np.uint8)], axis=2)
         assert np.array_equal(rgba, exp), (ct, w, h)
+
+
+@pytest.mark.parametrize("nwd", [2, 4, 8])
+def test_defilter_kernel_several_wavefronts_per_image(emu, nwd):
+    """debig_png_defilter_kernel<NWD>: the bands of one image pipelined through NWD wavefronts (band
+    k+1 runs about 80 groups behind band k and takes the row above it from the output).  Images
+    with more bands than wavefronts, rows shorter and longer than the pipeline distance, a palette
+    image (stays on one wavefront), and a bad filter byte in a late band (fails the image with
+    the first bad row, whichever wavefront meets it)."""
+    rng = np.random.default_rng(500 + nwd)
+    for ct, w, h in [(6, 3, 200), (6, 70, 130), (6, 700, 64 * nwd + 70), (2, 90, 64 * nwd + 3), (6, 1300, 129), (3, 50, 200)]:
+        bpp = {6: 4, 3: 1, 2: 3}[ct]
+        pal = rng.integers(0, 256, 768, dtype=np.uint8) if ct == 3 else None
+        stream = rng.integers(0, 256, h * (w * bpp + 1), dtype=np.uint8)
+        stream[:: w * bpp + 1] = rng.integers(0, 5, h)
+        want = _spec_defilter(stream, w, h, bpp).reshape(h, w, bpp)
+        rgba = _emu_defilter(emu, stream.tobytes(), w, h, ct, pal, nwd=nwd).reshape(h, w, 4)
+        if ct == 6:
+            exp = want
+        elif ct == 2:
+            exp = np.concatenate([want, np.full((h, w, 1), 255, np.uint8)], axis=2)
+        else:
+            idx = want[:, :, 0].astype(np.int64)
+            exp = np.stack([pal[idx], pal[256 + idx], pal[512 + idx], np.full((h, w), 255, np.uint8)], axis=2)
+        assert np.array_equal(rgba, exp), (ct, w, h, nwd)
+    w, h = 40, 64 * nwd + 100
+    stream = rng.integers(0, 256, h * (w * 4 + 1), dtype=np.uint8)
+    stream[:: w * 4 + 1] = rng.integers(0, 5, h)
+    for bad in (64 * nwd + 17, 70):
+        stream[bad * (w * 4 + 1)] = 9
+    assert _emu_defilter(emu, stream.tobytes(), w, h, 6, nwd=nwd, expect_good=0) == 70
 
 
 def test_p3_rgb_replay_kernel_matches_reference_digest(emu):

@@ -98,14 +98,25 @@ extern "C" int emu_inflate_split_batch(const void *in, void *out, const debig_st
     return 0;
 }
 
+extern "C" int emu_png_defilter_batch_w(const void *streams_arena, void *rgba_arena, const debig_png_image *images,
+                                        debig_png_result *results, uint32_t n, uint32_t nwd)
+{
+    if (nwd == 8)
+        EMU_LAUNCH(debig_png_defilter_kernel<8>, n, 512, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images, results, n);
+    else if (nwd == 4)
+        EMU_LAUNCH(debig_png_defilter_kernel<4>, n, 256, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images, results, n);
+    else if (nwd == 2)
+        EMU_LAUNCH(debig_png_defilter_kernel<2>, n, 128, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images, results, n);
+    else
+        EMU_LAUNCH(debig_png_defilter_kernel<1>, n, 64, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images, results, n);
+    EMU_LAUNCH(debig_png_p3_kernel, n, PNG_P3_THREADS, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images,
+               results, n);
+    return 0;
+}
 extern "C" int emu_png_defilter_batch(const void *streams_arena, void *rgba_arena, const debig_png_image *images,
                                       debig_png_result *results, uint32_t n)
 {
-    EMU_LAUNCH(debig_png_defilter_kernel, n, 64, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images,
-               results, n);
-    EMU_LAUNCH(debig_png_p3_kernel, n, 64, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images,
-               results, n);
-    return 0;
+    return emu_png_defilter_batch_w(streams_arena, rgba_arena, images, results, n, 1);
 }
 
 extern "C" int emu_checksum_batch(const void *arena, const debig_span *spans, uint32_t *out, uint32_t n, uint32_t kind)
