@@ -341,7 +341,7 @@ def main():
         blk = torch.from_numpy(in_block).to(dev)
         batch.d_in = blk.repeat(reps)
         batch.d_out = torch.zeros(out_block * reps, dtype=torch.uint8, device=dev)
-        batch.order, batch.planned_waves = None, 0
+        batch.order, batch.planned_waves, batch.d_ws = None, 0, None
         batch.d_streams = torch.from_numpy(streams.view(np.uint8).reshape(-1)).to(dev)
         from debigulator_amd.batch import RESULT_DTYPE
         from debigulator_amd import _native
