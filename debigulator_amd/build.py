@@ -31,6 +31,7 @@ def build(force=False, verbose=False, extra_defs=(), out=None):
     target = LIB if out is None else os.path.join(LIBDIR, out)
     root = os.path.dirname(HERE)
     deps = (glob.glob(os.path.join(CSRC, "*")) + glob.glob(os.path.join(CSRC, "host", "*")) +
+            glob.glob(os.path.join(CSRC, "compat", "*")) +
             glob.glob(os.path.join(root, "include", "*.h")))
     if not force and not _newer(target, deps):
         return target
@@ -58,6 +59,15 @@ def build(force=False, verbose=False, extra_defs=(), out=None):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    if out is None:
+        # optional static archive with the literal `inflate` symbol (csrc/compat/debig_compat.c)
+        co = os.path.join(odir, "debig_compat.o")
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-std=c11", "-Wall", "-Wextra", "-c",
+                               os.path.join(CSRC, "compat", "debig_compat.c"), "-o", co])
+        ar = os.path.join(LIBDIR, "libdebig_compat.a")
+        if os.path.exists(ar):
+            os.remove(ar)
+        subprocess.check_call(["ar", "rcs", ar, co])
     return target
 
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <mutex>
 #include "../../include/debig_hip.h"
 
 #include "inflate_kernel.inc"
@@ -31,10 +32,34 @@ struct FixedTabs {
     uint32_t *one, *mw, *scan; /* scan: the scan kernel's 16-bit format */
 };
 static FixedTabs g_fixed_tabs[64];
-static const FixedTabs *fixed_tables(hipStream_t s)
+static std::mutex g_init_mutex; /* the lazy per-device initialisations below: the drop-in API allows 10 concurrent thread ids */
+// the device the work is launched on: the stream's (a caller may pass a stream of another
+// device than the thread's current one), else the current device
+static int launch_device(hipStream_t s)
 {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (s != nullptr && hipStreamGetDevice(s, &dev) == hipSuccess) return dev;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    return dev;
+}
+struct DeviceGuard { /* allocations and table kernels happen on the launch device */
+    int prev = -1, dev = -1;
+    explicit DeviceGuard(int d) : dev(d)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (d >= 0 && d != prev) (void)hipSetDevice(d);
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
+static const FixedTabs *fixed_tables(hipStream_t s)
+{
+    const int dev = launch_device(s);
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    DeviceGuard guard(dev);
     FixedTabs *f = &g_fixed_tabs[dev];
     if (f->one && f->mw && f->scan) return f;
     uint32_t *a = nullptr, *b = nullptr, *c = nullptr;
@@ -45,7 +70,7 @@ static const FixedTabs *fixed_tables(hipStream_t s)
     hipLaunchKernelGGL(debig_fixed_tables_kernel<2>, dim3(1), dim3(64), 0, s, b);
     hipLaunchKernelGGL(debig_scan_fixed_tables_kernel, dim3(1), dim3(64), 0, s, c);
     // later launches may use other streams: make the tables globally visible first
-    if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); return nullptr; }
     f->one = a;
     f->mw = b;
     f->scan = c;
@@ -55,13 +80,15 @@ static const FixedTabs *fixed_tables(hipStream_t s)
 static CkTables *g_ck_tabs[64];
 static CkTables *checksum_tables(hipStream_t s)
 {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    const int dev = launch_device(s);
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    DeviceGuard guard(dev);
     if (g_ck_tabs[dev]) return g_ck_tabs[dev];
     CkTables *p = nullptr;
     if (hipMalloc(&p, sizeof(CkTables)) != hipSuccess) return nullptr;
     hipLaunchKernelGGL(debig_checksum_tables_kernel, dim3(1), dim3(CK_THREADS), 0, s, p);
-    if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(p); return nullptr; }
     g_ck_tabs[dev] = p;
     return p;
 }
@@ -72,6 +99,7 @@ int debig_hip_checksum_batch(const void *d_arena, const debig_span *d_spans, uin
                              uint32_t n, uint32_t kind, void *hip_stream)
 {
     if (n == 0) return 0;
+    DeviceGuard launch_guard(launch_device((hipStream_t)hip_stream)); /* kernels go to the stream's device */
     CkTables *t = checksum_tables((hipStream_t)hip_stream);
     if (!t) return (int)hipErrorOutOfMemory;
     hipLaunchKernelGGL(debig_checksum_kernel, dim3(n), dim3(CK_THREADS), 0, (hipStream_t)hip_stream,
@@ -83,6 +111,7 @@ int debig_hip_gather(const void *d_src_arena, void *d_dst_arena, const debig_cop
                      void *hip_stream)
 {
     if (n == 0) return 0;
+    DeviceGuard launch_guard(launch_device((hipStream_t)hip_stream)); /* kernels go to the stream's device */
     hipLaunchKernelGGL(debig_gather_kernel, dim3(n), dim3(CK_THREADS), 0, (hipStream_t)hip_stream,
                        (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, d_copies, n);
     return (int)hipGetLastError();
@@ -123,10 +152,12 @@ struct DefaultWs {
     uint64_t bytes;
 };
 static DefaultWs g_default_ws[64];
-static const DefaultWs *default_workspace(void)
+static const DefaultWs *default_workspace(hipStream_t s)
 {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    const int dev = launch_device(s);
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    DeviceGuard guard(dev);
     DefaultWs *w = &g_default_ws[dev];
     if (w->ptr) return w;
     uint64_t mb = 1024;
@@ -201,10 +232,12 @@ struct SideLane {
     int ready;
 };
 static SideLane g_side[64];
-static SideLane *side_lane(void)
+static SideLane *side_lane(hipStream_t s)
 {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    const int dev = launch_device(s);
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    DeviceGuard guard(dev);
     SideLane *l = &g_side[dev];
     if (l->ready) return l;
     if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
@@ -228,6 +261,7 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
                                void *d_workspace, uint64_t workspace_bytes, void *hip_stream)
 {
     if (n == 0) return 0;
+    DeviceGuard launch_guard(launch_device((hipStream_t)hip_stream)); /* kernels go to the stream's device */
     if (waves_per_stream == 0) waves_per_stream = auto_waves_per_stream(n);
     const int mixed = waves_per_stream == DEBIG_WAVES_LARGE4_SMALL1 || waves_per_stream == DEBIG_WAVES_LARGE4_SMALL2;
     if (!mixed && waves_per_stream != 1 && waves_per_stream != 2 && waves_per_stream != 4 && waves_per_stream != 8 &&
@@ -238,7 +272,7 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
     if (!ft) return (int)hipErrorOutOfMemory;
     if (waves_per_stream == DEBIG_WAVES_SPLIT) {
         if (!d_workspace) {
-            const DefaultWs *w = default_workspace();
+            const DefaultWs *w = default_workspace(s);
             if (w) { d_workspace = w->ptr; workspace_bytes = w->bytes; }
         }
         int rc = d_workspace ? launch_split(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes) : -1;
@@ -249,7 +283,7 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
 
     // large streams 4-wide on the side stream, small ones beside them on the caller's stream;
     // the caller's stream continues only when both are done
-    SideLane *l = side_lane();
+    SideLane *l = side_lane(s);
     if (!l) return (int)hipErrorOutOfMemory;
     hipError_t e;
     if ((e = hipEventRecord(l->fork, s)) != hipSuccess) return (int)e;
@@ -300,6 +334,7 @@ int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena
                                  uint32_t n, void *hip_stream)
 {
     if (n == 0) return 0;
+    DeviceGuard launch_guard(launch_device((hipStream_t)hip_stream)); /* kernels go to the stream's device */
     const uint32_t nwd = defilter_waves(n);
     hipStream_t s = (hipStream_t)hip_stream;
 #define DEFILTER_LAUNCH(W)                                                                              \

@@ -183,3 +183,14 @@ def test_multi_device_shard_partition_host_only(native_lib):
             seen += got
         assert sorted(seen) == list(range(n))
     assert f(10, 0, 0, None) == 0 and f(10, 4, 4, None) == 0
+
+
+def test_compat_archive_has_the_literal_inflate_symbol(native_lib):
+    """SURVEY 8b rule 3: the plain `inflate` symbol exists ONLY in the optional static archive
+    (debigulator_amd/lib/libdebig_compat.a), as a forwarder to debig_inflate."""
+    from debigulator_amd import _native
+
+    ar = os.path.join(os.path.dirname(_native.LIB_PATH), "libdebig_compat.a")
+    assert os.path.exists(ar), "python -m debigulator_amd.build makes it"
+    out = os.popen(f"nm {ar}").read()
+    assert " T inflate" in out and " U debig_inflate" in out

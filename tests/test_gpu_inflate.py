@@ -230,8 +230,10 @@ def test_large_streams_every_width(gpu_device):
 def test_p2_aliasing_replay_every_width(gpu_device):
     """decode_png's buffer-aliasing replay (parameters p2_s0 / p2_est of
     debig_stream) is part of the inflate kernel: all widths must produce the same, replayed,
-    stream.  The 4-wavefront result is pinned to the reference's digest by
-    test_gpu_dropin.py (decode_png of one file runs that width)."""
+    stream.  This test only says "all widths agree"; the replayed bytes themselves are pinned to the
+    reference's digest of phoebus.png by test_gpu_dropin.py::test_decode_png_resources_match_reference
+    (decode_png of a single file runs 8 wavefronts wide) and, for widths 1, 4 and the scan / LZ77
+    pair, by tests/test_emulator_kernels.py::test_p2_aliasing_replay_matches_reference_digest."""
     import os
 
     gold = os.path.join(os.path.dirname(__file__), "golden", "resources")
