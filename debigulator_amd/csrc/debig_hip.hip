@@ -63,9 +63,9 @@ static const FixedTabs *fixed_tables(hipStream_t s)
     FixedTabs *f = &g_fixed_tabs[dev];
     if (f->one && f->mw && f->scan) return f;
     uint32_t *a = nullptr, *b = nullptr, *c = nullptr;
-    if (hipMalloc(&a, sizeof(CodeTabsT<TabCfg<1>::PBL>)) != hipSuccess) return nullptr;
-    if (hipMalloc(&b, sizeof(CodeTabsT<TabCfg<2>::PBL>)) != hipSuccess) { (void)hipFree(a); return nullptr; }
-    if (hipMalloc(&c, sizeof(CodeTabsT<TabCfg<1>::PBL, uint16_t>)) != hipSuccess) { (void)hipFree(a); (void)hipFree(b); return nullptr; }
+    if (hipMalloc(&a, sizeof(decltype(WaveLdsT<1>::t))) != hipSuccess) return nullptr;
+    if (hipMalloc(&b, sizeof(decltype(WaveLdsT<2>::t))) != hipSuccess) { (void)hipFree(a); return nullptr; }
+    if (hipMalloc(&c, sizeof(decltype(ScanLds::t))) != hipSuccess) { (void)hipFree(a); (void)hipFree(b); return nullptr; }
     hipLaunchKernelGGL(debig_fixed_tables_kernel<1>, dim3(1), dim3(64), 0, s, a);
     hipLaunchKernelGGL(debig_fixed_tables_kernel<2>, dim3(1), dim3(64), 0, s, b);
     hipLaunchKernelGGL(debig_scan_fixed_tables_kernel, dim3(1), dim3(64), 0, s, c);

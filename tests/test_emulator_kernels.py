@@ -518,3 +518,41 @@ def test_split_path_hands_back_what_does_not_fit_its_workspace(emu, oracle):
             assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
     assert 0 not in seen or len(seen) > 1  # the small workspaces really sent streams back
     assert max(seen) >= len(raws) - 1
+
+
+@pytest.mark.parametrize("nw", [1, 2, 8, eb.SPLIT])
+def test_long_codes_take_the_second_level_tables(emu, oracle, nw):
+    """Codes longer than the direct tables (10/11 bits literal/length, 9 bits distance) are decoded
+    through second-level tables linked from the direct table (CodeTabsT::sub_tab): geometric byte
+    distributions give literal codes up to 15 bits, far distances with rare lengths give long
+    distance codes; a pathological code whose second-level tables do not fit takes the canonical
+    probe.  Every kernel width, against the oracle (which is pinned to the reference on K9's 13..15
+    bit codes and on the zlib corpus)."""
+    rng = np.random.default_rng(77)
+    raws, caps = [], []
+    for it in range(6):
+        n = 30000 + 5000 * it
+        # literal alphabet with probabilities 2^-1 .. 2^-15 and a uniform tail: long literal codes
+        p = np.array([2.0 ** -(1 + (k % 15)) for k in range(60)] + [1e-5] * 196)
+        data = rng.choice(256, size=n, p=p / p.sum()).astype(np.uint8).tobytes()
+        strat = [zlib.Z_HUFFMAN_ONLY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED][it % 3]
+        c = zlib.compressobj(9, zlib.DEFLATED, -15, 9, strat)
+        raws.append(c.compress(data) + c.flush())
+        caps.append(n + 1)
+    # long distance codes: most matches at a handful of distances, a few anywhere in 32 KiB
+    base = rng.integers(0, 256, 40000, dtype=np.uint8)
+    buf = bytearray(base.tobytes())
+    for k in range(3000):
+        src = rng.integers(0, 200) if k % 50 else rng.integers(0, 30000)
+        dst = rng.integers(32000, 39000)
+        buf[dst:dst + 6] = buf[dst - src - 6:dst - src] if dst - src - 6 >= 0 else buf[dst:dst + 6]
+    c = zlib.compressobj(9, zlib.DEFLATED, -15, 9)
+    raws.append(c.compress(bytes(buf)) + c.flush())
+    caps.append(len(buf) + 1)
+    want = [oracle.inflate(r, c, want_stats=True) for r, c in zip(raws, caps)]
+    outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, out_misalign=5)
+    for i, ((good, final, out, r), (g, f, o, st)) in enumerate(zip(outs, want)):
+        if st.ub_flags:
+            continue
+        assert (good, final, out) == (g, f, o), (nw, i)
+    assert sum(1 for w in want if w[0] == 1) >= 5

@@ -31,7 +31,7 @@ static int emu_inflate_1(const void *in, void *out, const debig_stream *streams,
     if (grid == 0 || grid > n) grid = n;
     static uint32_t *ft = nullptr;
     if (!ft) {
-        ft = (uint32_t *)calloc(1, sizeof(CodeTabsT<TabCfg<1>::PBL>));
+        ft = (uint32_t *)calloc(1, sizeof(decltype(WaveLdsT<1>::t)));
         EMU_LAUNCH(debig_fixed_tables_kernel<1>, 1, 64, ft);
     }
     EMU_LAUNCH(debig_inflate_kernel, grid, 64, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft, cls);
@@ -46,7 +46,7 @@ extern "C" int emu_inflate_batch_cls(const void *in, void *out, const debig_stre
     if (grid == 0 || grid > n) grid = n;
     static uint32_t *ft = nullptr;
     if (!ft) {
-        ft = (uint32_t *)calloc(1, sizeof(CodeTabsT<TabCfg<2>::PBL>));
+        ft = (uint32_t *)calloc(1, sizeof(decltype(WaveLdsT<2>::t)));
         EMU_LAUNCH(debig_fixed_tables_kernel<2>, 1, 64, ft);
     }
     if (nw == 2)
@@ -67,12 +67,12 @@ extern "C" int emu_inflate_split_batch(const void *in, void *out, const debig_st
 {
     static uint32_t *ft = nullptr;
     if (!ft) {
-        ft = (uint32_t *)calloc(1, sizeof(CodeTabsT<TabCfg<1>::PBL>));
+        ft = (uint32_t *)calloc(1, sizeof(decltype(WaveLdsT<1>::t)));
         EMU_LAUNCH(debig_fixed_tables_kernel<1>, 1, 64, ft);
     }
     static uint32_t *fts = nullptr;
     if (!fts) {
-        fts = (uint32_t *)calloc(1, sizeof(CodeTabsT<TabCfg<1>::PBL, uint16_t>));
+        fts = (uint32_t *)calloc(1, sizeof(decltype(ScanLds::t)));
         EMU_LAUNCH(debig_scan_fixed_tables_kernel, 1, 64, fts);
     }
     const uint64_t slots_bytes = ((uint64_t)n * sizeof(debig_ws_slot) + 255) / 256 * 256;
