@@ -35,6 +35,7 @@ class DebigPngResult(C.Structure):
 
 
 WAVES_SPLIT = 0x10  # include/debig_hip.h: DEBIG_WAVES_SPLIT
+WAVES_CHUNKED = 0x20  # include/debig_hip.h: DEBIG_WAVES_CHUNKED
 
 _lib = None
 
@@ -66,6 +67,8 @@ def lib():
     L.debig_hip_inflate_batch_ws.argtypes = [vp, vp, vp, vp, u32, u32, vp, u64, vp]
     L.debig_hip_inflate_workspace_bytes.restype = u64
     L.debig_hip_inflate_workspace_bytes.argtypes = [u64, u32]
+    L.debig_hip_inflate_chunked_workspace_bytes.restype = u64
+    L.debig_hip_inflate_chunked_workspace_bytes.argtypes = [u64, u64, u32]
     L.debig_hip_png_defilter_batch.restype = C.c_int
     L.debig_hip_png_defilter_batch.argtypes = [vp, vp, vp, vp, u32, vp]
     L.debig_hip_device_count.restype = C.c_int

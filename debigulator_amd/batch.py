@@ -92,6 +92,8 @@ class DeviceBatch:
         self.d_results = torch.zeros(self.n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
         self.lib = N.lib()
         self.d_ws = None  # token workspace of the scan / LZ77 kernel pair, allocated on first use
+        self.dev_streams_host = dev_streams
+        self.chunk_groups = None  # WAVES_CHUNKED: [(first, count)] stream groups that fit the workspace
 
     @classmethod
     def from_streams(cls, raws, caps, device="cuda:0", plan=False, **kw):
@@ -108,6 +110,10 @@ class DeviceBatch:
             stream = torch.cuda.current_stream(self.device)
         if waves_per_stream == 0 and self.planned_waves and not os.environ.get("DEBIG_WAVES_PER_STREAM"):
             waves_per_stream = self.planned_waves
+        if waves_per_stream == 0 and int(os.environ.get("DEBIG_WAVES_PER_STREAM", "0"), 0) == N.WAVES_CHUNKED:
+            waves_per_stream = N.WAVES_CHUNKED
+        if waves_per_stream == N.WAVES_CHUNKED:
+            return self._launch_chunked(stream)
         ws_ptr, ws_bytes = None, 0
         if waves_per_stream == N.WAVES_SPLIT or (waves_per_stream == 0 and self.n > 1024 and
                                                  not os.environ.get("DEBIG_WAVES_PER_STREAM")):
@@ -121,6 +127,37 @@ class DeviceBatch:
                                                  self.n, waves_per_stream, ws_ptr, ws_bytes,
                                                  C.c_void_p(stream.cuda_stream))
         N.check(rc, "debig_hip_inflate_batch_ws")
+
+    def _launch_chunked(self, stream):
+        """The chunk-parallel path for few large streams: the batch goes through in groups of
+        streams whose workspace need (debig_hip_inflate_chunked_workspace_bytes) fits
+        DEBIG_CHUNKED_WS_MB (default 40960) MiB; one workspace, reused group after group."""
+        torch = self.torch
+        if self.chunk_groups is None:
+            cap = int(os.environ.get("DEBIG_CHUNKED_WS_MB", "40960")) << 20
+            need = lambda a, b, c: int(self.lib.debig_hip_inflate_chunked_workspace_bytes(int(a), int(b), int(c)))
+            groups, first, tin, tout, biggest = [], 0, 0, 0, 0
+            ds = self.dev_streams_host
+            for i in range(self.n):
+                a, b = int(ds[i]["in_len"]), int(ds[i]["out_cap"])
+                if i > first and need(tin + a, tout + b, i - first + 1) > cap:
+                    groups.append((first, i - first))
+                    biggest = max(biggest, need(tin, tout, i - first))
+                    first, tin, tout = i, 0, 0
+                tin += a
+                tout += b
+            groups.append((first, self.n - first))
+            biggest = max(biggest, need(tin, tout, self.n - first))
+            self.chunk_groups = groups
+            self.d_ws_chunked = torch.empty(biggest, dtype=torch.uint8, device=self.device)
+        ssz, rsz = STREAM_DTYPE.itemsize, RESULT_DTYPE.itemsize
+        for first, count in self.chunk_groups:
+            rc = self.lib.debig_hip_inflate_batch_ws(self.d_in.data_ptr(), self.d_out.data_ptr(),
+                                                     self.d_streams.data_ptr() + first * ssz,
+                                                     self.d_results.data_ptr() + first * rsz, count, N.WAVES_CHUNKED,
+                                                     self.d_ws_chunked.data_ptr(), self.d_ws_chunked.numel(),
+                                                     C.c_void_p(stream.cuda_stream))
+            N.check(rc, "debig_hip_inflate_batch_ws")
 
     def results(self):
         """results in the caller's stream order"""

@@ -9,6 +9,7 @@
 #include "inflate_kernel.inc"
 #include "inflate_mw_kernel.inc"
 #include "inflate_split_kernel.inc"
+#include "inflate_chunk_kernel.inc"
 #include "png_kernel.inc"
 #include "checksum_kernel.inc"
 
@@ -206,6 +207,46 @@ static int launch_split(hipStream_t s, const void *d_in, void *d_out, const debi
     return 0;
 }
 
+// ---- the chunk-parallel path for large streams (inflate_chunk_kernel.inc): eleven small launches,
+// no host synchronisation; sizes live in device memory, so every grid is laid out for the number of
+// chunk tasks the workspace could hold and surplus workgroups leave at once.  Returns 0, a
+// hipError_t, or -1 when the workspace is too small to try.
+static uint32_t chunk_bytes_override()
+{
+    // DEBIG_CHUNK_BYTES: compressed bytes per chunk task (default: by batch size, 32..256 KiB)
+    static int env_read = 0;
+    static uint32_t env_val = 0;
+    if (!env_read) {
+        const char *e = getenv("DEBIG_CHUNK_BYTES");
+        if (e && *e) env_val = (uint32_t)strtoul(e, nullptr, 0);
+        env_read = 1;
+    }
+    return env_val;
+}
+static int launch_chunked(hipStream_t s, const void *d_in, void *d_out, const debig_stream *d_streams,
+                          debig_result *d_results, uint32_t n, const FixedTabs *tabs, void *ws_, uint64_t ws_bytes)
+{
+    const uint32_t mt = ck_max_tasks(ws_bytes, n);
+    if (mt == 0) return -1;
+    uint8_t *ws = (uint8_t *)ws_;
+    const uint8_t *in = (const uint8_t *)d_in;
+    uint8_t *out = (uint8_t *)d_out;
+    hipLaunchKernelGGL(debig_ck_plan_kernel, dim3(1), dim3(1024), 0, s, d_streams, n, ws, ws_bytes, mt, chunk_bytes_override());
+    hipLaunchKernelGGL(debig_ck_find_kernel, dim3(mt), dim3(64), 0, s, in, d_streams, n, ws, mt | (getenv("CKDBG") ? (uint32_t)atoi(getenv("CKDBG")) << 30 : 0u));
+    hipLaunchKernelGGL(debig_ck_bounds_kernel, dim3((n + 63u) / 64u), dim3(64), 0, s, n, ws);
+    hipLaunchKernelGGL(debig_ck_carve_kernel, dim3(1), dim3(1024), 0, s, d_streams, n, ws, mt);
+    hipLaunchKernelGGL(debig_ck_scan_kernel, dim3(mt), dim3(64), 0, s, in, d_streams, n, (const uint32_t *)tabs->scan, ws, mt);
+    hipLaunchKernelGGL(debig_ck_chain_kernel, dim3((n + 63u) / 64u), dim3(64), 0, s, d_streams, n, ws, mt);
+    hipLaunchKernelGGL(debig_ck_place_kernel, dim3(1), dim3(1024), 0, s, n, ws);
+    hipLaunchKernelGGL(debig_ck_lz_kernel, dim3(2u * mt), dim3(64), 0, s, in, out, d_streams, n, ws, mt);
+    hipLaunchKernelGGL(debig_ck_window_kernel, dim3(n), dim3(CK_WIN_THREADS), 0, s, (const uint8_t *)out, d_streams, n, ws, mt);
+    hipLaunchKernelGGL(debig_ck_translate_kernel, dim3(mt * CK_TR_PARTS), dim3(CK_TR_THREADS), 0, s, out, d_streams, n, ws, mt);
+    hipLaunchKernelGGL(debig_ck_finish_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, n, (const uint8_t *)ws, d_results);
+    hipLaunchKernelGGL(debig_inflate_kernel, dim3(n), dim3(64), 0, s, in, out, d_streams, d_results, n, tabs->one,
+                       DEBIG_CLASS_RETRY);
+    return (int)hipGetLastError();
+}
+
 static int launch_inflate(uint32_t width, uint32_t cls, hipStream_t s, const void *d_in, void *d_out,
                           const debig_stream *d_streams, debig_result *d_results, uint32_t n, const FixedTabs *tabs)
 {
@@ -256,6 +297,15 @@ uint64_t debig_hip_inflate_workspace_bytes(uint64_t total_in_bytes, uint32_t n)
     return align_up((uint64_t)group * (sizeof(debig_ws_slot) + 24576u) + per_group_in * 9u, 4096);
 }
 
+uint64_t debig_hip_inflate_chunked_workspace_bytes(uint64_t total_in_bytes, uint64_t total_out_bytes, uint32_t n)
+{
+    // tables + tokens (about 9 x the compressed bytes) + two planes of the output + per chunk task
+    // (32 KiB of input at the smallest chunk size) a window, two synthetic histories and token slack
+    const uint64_t tasks = total_in_bytes / CK_MIN_CHUNK + n;
+    return align_up((uint64_t)n * 4224u + tasks * (128u + 24576u + 98304u) + total_in_bytes * 10u + total_out_bytes * 2u +
+                        (total_out_bytes >> 6) + (1u << 20), 4096);
+}
+
 int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream *d_streams,
                                debig_result *d_results, uint32_t n, uint32_t waves_per_stream,
                                void *d_workspace, uint64_t workspace_bytes, void *hip_stream)
@@ -265,11 +315,20 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
     if (waves_per_stream == 0) waves_per_stream = auto_waves_per_stream(n);
     const int mixed = waves_per_stream == DEBIG_WAVES_LARGE4_SMALL1 || waves_per_stream == DEBIG_WAVES_LARGE4_SMALL2;
     if (!mixed && waves_per_stream != 1 && waves_per_stream != 2 && waves_per_stream != 4 && waves_per_stream != 8 &&
-        waves_per_stream != DEBIG_WAVES_SPLIT)
+        waves_per_stream != DEBIG_WAVES_SPLIT && waves_per_stream != DEBIG_WAVES_CHUNKED)
         return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)hip_stream;
     const FixedTabs *ft = fixed_tables(s);
     if (!ft) return (int)hipErrorOutOfMemory;
+    if (waves_per_stream == DEBIG_WAVES_CHUNKED) {
+        if (!d_workspace) {
+            const DefaultWs *w = default_workspace(s);
+            if (w) { d_workspace = w->ptr; workspace_bytes = w->bytes; }
+        }
+        int rc = d_workspace ? launch_chunked(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes) : -1;
+        if (rc >= 0) return rc;
+        waves_per_stream = n <= 256u ? 8u : n <= 512u ? 4u : n <= 1024u ? 2u : 1u; /* no usable workspace */
+    }
     if (waves_per_stream == DEBIG_WAVES_SPLIT) {
         if (!d_workspace) {
             const DefaultWs *w = default_workspace(s);

@@ -123,6 +123,18 @@ int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d
  *              one of DEBIG_WORKSPACE_MB MiB, default 1024); a stream that does not fit its share
  *              is decoded by the one-kernel path in the same call. */
 #define DEBIG_WAVES_SPLIT 0x10u
+/*   DEBIG_WAVES_CHUNKED
+ *              a FEW LARGE streams (hundreds of big PNG images): every stream is cut at DEFLATE
+ *              block boundaries into chunk tasks of 32..256 KiB of input, found by looking for
+ *              dynamic block headers, and the tasks go through the scan / LZ77 kernels side by
+ *              side; a task does not know the 32 KiB of output in front of it, so its matches
+ *              are replayed against two synthetic histories and translated once the true window
+ *              is known (csrc/inflate_chunk_kernel.inc).  Needs workspace:
+ *              debig_hip_inflate_chunked_workspace_bytes(); callers with more data than
+ *              workspace pass the batch in groups.  Streams the path cannot take (no dynamic
+ *              blocks, a block longer than the workspace share, a failing stream, any doubt)
+ *              are decoded by the one-kernel path in the same call.  Never picked by 0. */
+#define DEBIG_WAVES_CHUNKED 0x20u
 int debig_hip_inflate_batch_ex(const void *d_in, void *d_out, const debig_stream *d_streams,
                                debig_result *d_results, uint32_t n, uint32_t waves_per_stream,
                                void *hip_stream);
@@ -134,6 +146,9 @@ int debig_hip_inflate_batch_ex(const void *d_in, void *d_out, const debig_stream
  * path.  d_workspace = NULL: the internal cached workspace.  The workspace holds no state between
  * calls. */
 uint64_t debig_hip_inflate_workspace_bytes(uint64_t total_in_bytes, uint32_t n);
+/* workspace that lets DEBIG_WAVES_CHUNKED take every stream of a batch: total_out_bytes = the sum
+ * of the recipients (out_cap), which should be close to the decoded sizes */
+uint64_t debig_hip_inflate_chunked_workspace_bytes(uint64_t total_in_bytes, uint64_t total_out_bytes, uint32_t n);
 int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream *d_streams,
                                debig_result *d_results, uint32_t n, uint32_t waves_per_stream,
                                void *d_workspace, uint64_t workspace_bytes, void *hip_stream);

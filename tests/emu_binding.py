@@ -38,9 +38,13 @@ def load_emu(asan=False):
     L.emu_inflate_split_batch.restype = C.c_int
     L.emu_inflate_split_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
                                           C.POINTER(C.c_uint32)]
+    L.emu_inflate_chunked_batch.restype = C.c_int
+    L.emu_inflate_chunked_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
+                                            C.c_uint32, C.POINTER(C.c_uint32)]
     return L
 
 
+CHUNKED = 0x20  # nw code of the chunk-parallel path (include/debig_hip.h: DEBIG_WAVES_CHUNKED)
 SPLIT = 0x10  # nw code of the scan / LZ77 kernel pair (include/debig_hip.h: DEBIG_WAVES_SPLIT)
 last_split_retried = 0  # streams the pair handed to the one-kernel path in the last SPLIT call
 
@@ -75,10 +79,11 @@ def layout_batch(raws, caps, in_misalign=0, out_misalign=0, p2=None, flags=0):
     return in_arena, out_arena, streams, results, offs
 
 
-def emu_inflate(L, raws, caps, grid=0, nw=1, classes=None, ws_bytes=None, **kw):
+def emu_inflate(L, raws, caps, grid=0, nw=1, classes=None, ws_bytes=None, chunk_bytes=4096, **kw):
     """nw = 1: debig_inflate_kernel; nw = 2 / 4: debig_inflate_mw_kernel<nw> (one stream per
     workgroup of nw wavefronts).  classes = [(nw, cls), ...]: one launch per entry, each
     restricted to a stream class (1 small, 2 large), like the shim's mixed-width mode."""
+    global last_split_retried
     in_arena, out_arena, streams, results, offs = layout_batch(raws, caps, **kw)
     if classes is not None:
         rc = 0
@@ -86,12 +91,20 @@ def emu_inflate(L, raws, caps, grid=0, nw=1, classes=None, ws_bytes=None, **kw):
             rc |= L.emu_inflate_batch_cls(in_arena.ctypes.data, out_arena.ctypes.data, streams, results,
                                           len(raws), grid, w, cls)
     elif nw == SPLIT:
-        global last_split_retried
         if ws_bytes is None:
             ws_bytes = len(raws) * (32 + 24576) + 9 * sum(len(r) for r in raws)
         nr = C.c_uint32(0)
         rc = L.emu_inflate_split_batch(in_arena.ctypes.data, out_arena.ctypes.data, streams, results, len(raws),
                                        ws_bytes, C.byref(nr))
+        last_split_retried = nr.value
+    elif nw == CHUNKED:
+        if ws_bytes is None:
+            tasks = sum(len(r) // chunk_bytes + 1 for r in raws)
+            ws_bytes = (len(raws) * 8192 + tasks * (32768 * 4 + 24576) + 12 * sum(len(r) for r in raws) +
+                        3 * sum(min(c, 1032 * len(r)) for r, c in zip(raws, caps)))
+        nr = C.c_uint32(0)
+        rc = L.emu_inflate_chunked_batch(in_arena.ctypes.data, out_arena.ctypes.data, streams, results, len(raws),
+                                         ws_bytes, chunk_bytes, C.byref(nr))
         last_split_retried = nr.value
     elif nw == 1:
         rc = L.emu_inflate_batch(in_arena.ctypes.data, out_arena.ctypes.data, streams, results, len(raws), grid)

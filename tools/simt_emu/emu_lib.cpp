@@ -1,11 +1,14 @@
 /* DEVELOPMENT / TEST TOOLING: the product's HIP kernels compiled for the CPU lock-step
  * emulator (hip_emu.h).  Exposes the same batch entry points as libdebigulator_hip.so
  * (include/debig_hip.h) with an emu_ prefix and HOST pointers. */
+#include <stdio.h>
+#include <stdlib.h>
 #include "hip_emu.h"
 #include "../../include/debig_hip.h"
 #include "../../debigulator_amd/csrc/inflate_kernel.inc"
 #include "../../debigulator_amd/csrc/inflate_mw_kernel.inc"
 #include "../../debigulator_amd/csrc/inflate_split_kernel.inc"
+#include "../../debigulator_amd/csrc/inflate_chunk_kernel.inc"
 #include "../../debigulator_amd/csrc/png_kernel.inc"
 #include "../../debigulator_amd/csrc/checksum_kernel.inc"
 
@@ -93,6 +96,61 @@ extern "C" int emu_inflate_split_batch(const void *in, void *out, const debig_st
     uint32_t retried = 0;
     for (uint32_t i = 0; i < n; i++) retried += results[i].status == DEBIG_E_RETRY;
     if (n_retried) *n_retried = retried;
+    EMU_LAUNCH(debig_inflate_kernel, n, 64, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft, DEBIG_CLASS_RETRY);
+    free(ws);
+    return 0;
+}
+
+// the chunk-parallel path for large streams (inflate_chunk_kernel.inc), kernel by kernel as the
+// shim launches them; n_retried: streams handed to debig_inflate_kernel
+extern "C" int emu_inflate_chunked_batch(const void *in, void *out, const debig_stream *streams, debig_result *results,
+                                         uint32_t n, uint64_t ws_bytes, uint32_t chunk_bytes, uint32_t *n_retried)
+{
+    static uint32_t *ft = nullptr;
+    if (!ft) {
+        ft = (uint32_t *)calloc(1, sizeof(decltype(WaveLdsT<1>::t)));
+        EMU_LAUNCH(debig_fixed_tables_kernel<1>, 1, 64, ft);
+    }
+    static uint32_t *fts = nullptr;
+    if (!fts) {
+        fts = (uint32_t *)calloc(1, sizeof(decltype(ScanLds::t)));
+        EMU_LAUNCH(debig_scan_fixed_tables_kernel, 1, 64, fts);
+    }
+    const uint32_t mt = ck_max_tasks(ws_bytes, n);
+    if (mt == 0) return -1;
+    uint8_t *ws = (uint8_t *)aligned_alloc(256, (ws_bytes + 255) / 256 * 256);
+    memset(ws, 0xEE, ws_bytes); /* poison: nothing may be read before it is written */
+    EMU_LAUNCH(debig_ck_plan_kernel, 1, 1024, streams, n, ws, ws_bytes, mt, chunk_bytes);
+    EMU_LAUNCH(debig_ck_find_kernel, mt, 64, (const uint8_t *)in, streams, n, ws, mt);
+    EMU_LAUNCH(debig_ck_bounds_kernel, (n + 63) / 64, 64, n, ws);
+    EMU_LAUNCH(debig_ck_carve_kernel, 1, 1024, streams, n, ws, mt);
+    EMU_LAUNCH(debig_ck_scan_kernel, mt, 64, (const uint8_t *)in, streams, n, (const uint32_t *)fts, ws, mt);
+    EMU_LAUNCH(debig_ck_chain_kernel, (n + 63) / 64, 64, streams, n, ws, mt);
+    EMU_LAUNCH(debig_ck_place_kernel, 1, 1024, n, ws);
+    EMU_LAUNCH(debig_ck_lz_kernel, 2 * mt, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, ws, mt);
+    EMU_LAUNCH(debig_ck_window_kernel, n, CK_WIN_THREADS, (const uint8_t *)out, streams, n, ws, mt);
+    EMU_LAUNCH(debig_ck_translate_kernel, mt * CK_TR_PARTS, CK_TR_THREADS, (uint8_t *)out, streams, n, ws, mt);
+    EMU_LAUNCH(debig_ck_finish_kernel, (n + 255) / 256, 256, n, (const uint8_t *)ws, results);
+    uint32_t retried = 0;
+    for (uint32_t i = 0; i < n; i++) retried += results[i].status == DEBIG_E_RETRY;
+    if (n_retried) *n_retried = retried;
+    if (getenv("DEBIG_EMU_CK_DEBUG")) {
+        const debig_ck_hdr *h = (const debig_ck_hdr *)ws;
+        fprintf(stderr, "ck: tasks %u of %u, C %u, rows %llu recs %llu planes %llu\n", h->n_tasks, h->max_tasks, h->chunk_bytes,
+                (unsigned long long)h->total_rows, (unsigned long long)h->total_recs, (unsigned long long)h->planes_bytes);
+        for (uint32_t i = 0; i < n; i++) {
+            const debig_ck_stream &c = ck_streams(ws)[i];
+            fprintf(stderr, " stream %u: tasks %u+%u state %u final %u total %llu bad %u need %llu\n", i, c.first_task, c.n_tasks,
+                    c.state, c.final_task, (unsigned long long)c.total_out, c.bad, (unsigned long long)c.plane_need);
+            for (uint32_t k = 0; k < c.n_tasks; k++) {
+                const debig_ck_task &t = ck_tasks(ws, n)[c.first_task + k];
+                const debig_ws_slot &sl = ck_slots(ws, n, mt)[c.first_task + k];
+                fprintf(stderr, "   task %u: found %lld start %lld stop %lld live %u | slot state %u flags %u out %llu end %lld rows %u recs %u\n",
+                        k, (long long)t.found_bit, (long long)t.start_bit, (long long)t.stop_bit, t.live, sl.state, sl.flags,
+                        (unsigned long long)sl.out_total, (long long)sl.end_bit, sl.rows, sl.recs);
+            }
+        }
+    }
     EMU_LAUNCH(debig_inflate_kernel, n, 64, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft, DEBIG_CLASS_RETRY);
     free(ws);
     return 0;
