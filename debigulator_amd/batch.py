@@ -59,13 +59,16 @@ def pack_streams(raws, caps, in_align=16, out_align=16, in_skew=0, out_skew=0, p
 
 def plan_batch(streams):
     """Dispatch plan of one launch, the same rule as csrc/host/debig_ctx.h: debig_plan_batch.
-    Workgroups start in descriptor order; a batch of 513..1024 streams whose largest quarter
+    A batch of at most 1024 streams with 1 MiB of input or more per stream on average goes through
+    the chunk-parallel path.  Workgroups start in descriptor order; a batch of 513..1024 streams whose largest quarter
     holds at least half of the input bytes is launched longest first, 4 wavefronts wide.
     -> (order or None, waves_per_stream or 0)."""
     n = len(streams)
+    lens = streams["in_len"].astype(np.int64)
+    if 0 < n <= 1024 and int(lens.sum()) >= n << 20:  # few streams, >= 1 MiB of input each on average
+        return None, N.WAVES_CHUNKED                   # debig_ctx.h: debig_pick_waves
     if n <= 512 or n > 1024:
         return None, 0
-    lens = streams["in_len"].astype(np.int64)
     order = np.lexsort((np.arange(n), -lens))
     total, top = int(lens.sum()), int(lens[order[: n // 4]].sum())
     if total and top * 2 >= total:

@@ -1,5 +1,6 @@
 #include "debig_ctx.h"
 #include <pthread.h>
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -219,13 +220,46 @@ int debig_launch_inflate_planned(debig_ctx *c, const void *d_in_arena, const deb
     }
     if ((rc = debig_devbuf_reserve(&c->desc, (uint64_t)n * sizeof(debig_stream))) ||
         (rc = debig_devbuf_reserve(&c->res, (uint64_t)n * sizeof(debig_result))) ||
-        (rc = debig_hip_memcpy_h2d(c->desc.ptr, up, (uint64_t)n * sizeof(debig_stream), NULL)) ||
-        (rc = debig_hip_inflate_batch_ws(d_in_arena, c->out.ptr, (const debig_stream *)c->desc.ptr,
-                                         (debig_result *)c->res.ptr, n, w, ws_bytes ? c->ws.ptr : NULL, ws_bytes, NULL)) ||
-        (rc = debig_hip_memcpy_d2h(down, c->res.ptr, (uint64_t)n * sizeof(debig_result), NULL)) ||
-        (rc = debig_hip_stream_sync(NULL))) {
+        (rc = debig_hip_memcpy_h2d(c->desc.ptr, up, (uint64_t)n * sizeof(debig_stream), NULL))) {
         /* fall through to the cleanup */
-    } else if (permuted) {
+    } else if (w == DEBIG_WAVES_CHUNKED) {
+        /* chunk tasks need about 5 bytes of workspace per decoded byte: the batch goes through in
+         * groups of streams that fit DEBIG_CHUNKED_WS_MB (default 40960) MiB, launched back to back */
+        uint64_t cap = 40960ull << 20;
+        const char *e = getenv("DEBIG_CHUNKED_WS_MB");
+        if (e && *e) cap = strtoull(e, NULL, 0) << 20;
+        /* pass 0 sizes the largest group (one reservation: growing the buffer between launches would
+         * wait for the device), pass 1 launches */
+        uint64_t biggest = 0;
+        void *ws = NULL;
+        for (int pass = 0; pass < 2 && !rc; pass++) {
+            uint32_t first = 0;
+            while (first < n && !rc) {
+                uint64_t tin = 0, tout = 0, need = 0;
+                uint32_t cnt = 0;
+                while (first + cnt < n) {
+                    const uint64_t a = up[first + cnt].in_len, b = up[first + cnt].out_cap;
+                    const uint64_t nd = debig_hip_inflate_chunked_workspace_bytes(tin + a, tout + b, cnt + 1u);
+                    if (cnt && nd > cap) break;
+                    tin += a; tout += b; need = nd; cnt++;
+                }
+                if (need > cap) need = cap; /* one stream larger than the cap: the chunk path hands it back */
+                if (pass == 0) { if (need > biggest) biggest = need; }
+                else /* no workspace: the call falls back to whole workgroups per stream */
+                    rc = debig_hip_inflate_batch_ws(d_in_arena, c->out.ptr, (const debig_stream *)c->desc.ptr + first,
+                                                    (debig_result *)c->res.ptr + first, cnt, DEBIG_WAVES_CHUNKED, ws,
+                                                    ws ? need : 0, NULL);
+                first += cnt;
+            }
+            if (pass == 0) ws = debig_devbuf_reserve(&c->ws, biggest) ? NULL : c->ws.ptr;
+        }
+    } else {
+        rc = debig_hip_inflate_batch_ws(d_in_arena, c->out.ptr, (const debig_stream *)c->desc.ptr,
+                                        (debig_result *)c->res.ptr, n, w, ws_bytes ? c->ws.ptr : NULL, ws_bytes, NULL);
+    }
+    if (!rc) rc = debig_hip_memcpy_d2h(down, c->res.ptr, (uint64_t)n * sizeof(debig_result), NULL);
+    if (!rc) rc = debig_hip_stream_sync(NULL);
+    if (!rc && permuted) {
         for (uint32_t k = 0; k < n; k++) res[order[k]] = tmp[k];
     }
     free(order);

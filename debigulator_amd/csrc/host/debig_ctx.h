@@ -49,8 +49,18 @@ int debig_download_unpack(debig_ctx *c, const void *d_arena, uint8_t *const *dst
  * wavefronts each.  A big batch in which only a few streams are large: those 4-wide beside
  * the small ones 1-wide, so the longest stream does not set the run time (measured:
  * profiles/r01_mw_sweep.txt). */
+/* Few streams, large on average (a batch of big PNG images): cut them into chunk tasks
+ * (DEBIG_WAVES_CHUNKED).  Measured (profiles/r02_chunked.txt): 64 streams of 1.6 MB, 13.3 ms with
+ * 8 wavefronts per stream, 5.5 ms in chunk tasks; config 3's 1024 sample PNGs (0.43 MB on
+ * average) are 40 % slower in chunk tasks.  The line is drawn at 1 MiB of input per stream. */
+#define DEBIG_CHUNKED_MEAN_IN_BYTES (1u << 20)
 static inline uint32_t debig_pick_waves(const debig_stream *desc, uint32_t n)
 {
+    if (n <= 1024u) {
+        uint64_t total_in = 0;
+        for (uint32_t i = 0; i < n; i++) total_in += desc[i].in_len;
+        if (total_in >= (uint64_t)n * DEBIG_CHUNKED_MEAN_IN_BYTES) return DEBIG_WAVES_CHUNKED;
+    }
     if (n <= 256u) return 8u;
     if (n <= 512u) return 4u;
     if (n <= 1024u) return 2u;

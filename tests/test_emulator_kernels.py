@@ -556,3 +556,136 @@ def test_long_codes_take_the_second_level_tables(emu, oracle, nw):
             continue
         assert (good, final, out) == (g, f, o), (nw, i)
     assert sum(1 for w in want if w[0] == 1) >= 5
+
+
+# ---------------------------------------------------------------- chunk-parallel path (inflate_chunk_kernel.inc)
+def _text(rng, nbytes):
+    words = [bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(2, 9))) for _ in range(400)]
+    out = bytearray()
+    while len(out) < nbytes:
+        out += rng.choice(words) + b" "
+    return bytes(out[:nbytes])
+
+
+def _raw(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, flush_every=0):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    if not flush_every:
+        return c.compress(data) + c.flush()
+    out = b""
+    for at in range(0, len(data), flush_every):
+        out += c.compress(data[at:at + flush_every]) + c.flush(zlib.Z_SYNC_FLUSH)
+    return out + c.flush()
+
+
+def _png_stream(seed, w, h):
+    png, _ = workload.make_png(seed, w, h, noise=workload.CFG4_NOISE)
+    at, z = 8, b""
+    while at + 8 <= len(png):
+        ln = int.from_bytes(png[at:at + 4], "big")
+        if png[at + 4:at + 8] == b"IDAT":
+            z += png[at + 8:at + 8 + ln]
+        at += 12 + ln
+    return z[2:-4]
+
+
+def test_chunked_path_cuts_large_streams_at_block_headers(emu, oracle):
+    """Streams of several blocks through DEBIG_WAVES_CHUNKED with 4 KiB chunks: every kind of block
+    sequence, recipients exact / too small, a stream without a place to cut (fixed blocks only) and
+    gate failures -- all equal to the oracle, and only the expected ones handed back."""
+    rng = random.Random(11)
+    nprng = np.random.default_rng(11)
+    text = _text(rng, 260000)
+    noise = nprng.integers(0, 256, 40000, dtype=np.uint8).tobytes()
+    cases = []  # (raw, cap, handed back?)
+    dyn, plain = workload.make_stream("dynamic", 7, size=150000)
+    cases.append((bytes(dyn), len(plain) + 77, False))
+    cases.append((_raw(text, 6), len(text), False))                                    # exact recipient
+    cases.append((_raw(text[:90000], 1), 90000 + 5, False))
+    cases.append((_raw(text[:120000] + noise + text[120000:200000], 9), 240000 + 64, False))  # stored blocks inside
+    cases.append((_raw(text[:150000], 6, flush_every=20000), 150000 + 3, False))       # empty stored blocks (sync flush)
+    cases.append((_png_stream(3, 200, 150), 200 * 150 * 4 + 150 + 9, False))
+    cases.append((_raw(text[:60000], 6) + nprng.integers(0, 256, 9000, dtype=np.uint8).tobytes(), 60000 + 16, False))  # bytes behind the final block
+    cases.append((_raw(text[:3000], 6), 3000, False))                                  # one task
+    cases.append((_raw(text[:80000], 6, zlib.Z_FIXED), 80000 + 1, False))              # no dynamic block to cut at: one task
+    cases.append((_raw(text[:100000], 6), 100000 - 10, True))                          # recipient too small
+    cases.append((_raw(noise, 6), len(noise) - 1000, True))                            # gate: recipient < input
+    raws, caps = [c[0] for c in cases], [c[1] for c in cases]
+    outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=eb.CHUNKED, chunk_bytes=4096, in_misalign=3, out_misalign=5)
+    assert eb.last_split_retried == sum(c[2] for c in cases)
+    one, _, _ = eb.emu_inflate(emu, raws, caps, nw=1)  # the one-kernel path: block count and end position
+    for i, (raw, cap, (good, final, out, r)) in enumerate(zip(raws, caps, outs)):
+        eg, ef, eo = oracle.inflate(raw, cap)[:3]
+        assert (good, final) == (eg, ef), i
+        assert out == eo, i
+        assert (r.n_blocks, r.in_end_bits, r.status) == (one[i][3].n_blocks, one[i][3].in_end_bits, one[i][3].status), i
+    for (io, oo), cap in zip(offs, caps):
+        assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
+
+
+def test_chunked_path_false_header_and_damage_go_to_the_one_kernel_path(emu, oracle):
+    """A byte-aligned copy of a real dynamic block inside a STORED block is what the block finder
+    looks for but not a block boundary: the chain check must refuse the stream (the one-kernel path
+    decodes it).  Damaged streams: whatever the chunk tasks make of the bytes behind the damage,
+    the result is the oracle's."""
+    rng = random.Random(12)
+    text = _text(rng, 200000)
+    decoy = _raw(text[:30000], 6)[:6000]          # starts with a dynamic block header at bit 0
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    a = c.compress(text[:60000]) + c.flush(zlib.Z_FULL_FLUSH)        # ends byte aligned
+    stored = b"\x00" + len(decoy).to_bytes(2, "little") + (len(decoy) ^ 0xffff).to_bytes(2, "little") + decoy
+    c2 = zlib.compressobj(6, zlib.DEFLATED, -15)
+    tail = c2.compress(text[60000:140000]) + c2.flush()
+    trap = a + stored + tail
+    want = text[:60000] + decoy + text[60000:140000]
+    assert zlib.decompress(trap, -15) == want
+    raws, caps = [trap], [len(want) + 11]
+    good_raw = _raw(text, 6)
+    for pos in (100, len(good_raw) // 3, len(good_raw) // 2, len(good_raw) - 3000):
+        bad = bytearray(good_raw)
+        bad[pos] ^= 0x10
+        raws.append(bytes(bad))
+        caps.append(len(text) + 100)
+    raws.append(good_raw[:len(good_raw) // 2])  # truncated: no final block
+    caps.append(len(text))
+    outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=eb.CHUNKED, chunk_bytes=4096)
+    assert outs[0][0] == 1 and outs[0][2] == want
+    assert eb.last_split_retried >= 2
+    for raw, cap, (good, final, out, r) in zip(raws, caps, outs):
+        eg, ef, eo, st = oracle.inflate(raw, cap, want_stats=True)
+        if st.ub_flags & (0x10 | 0x02):
+            continue
+        assert (good, final, out) == (eg, ef, eo)
+
+
+def test_chunked_path_small_workspace_hands_everything_back(emu, oracle):
+    rng = random.Random(13)
+    text = _text(rng, 120000)
+    raws = [_raw(text, 6), _raw(text[:50000], 9)]
+    caps = [len(text), 50000]
+    outs, _, _ = eb.emu_inflate(emu, raws, caps, nw=eb.CHUNKED, chunk_bytes=4096, ws_bytes=300000)
+    assert eb.last_split_retried >= 1
+    for raw, cap, (good, final, out, r) in zip(raws, caps, outs):
+        assert (good, final, out) == oracle.inflate(raw, cap)[:3]
+
+
+def test_chunked_path_p2_aliasing_replay_in_the_last_task(emu):
+    """phoebus.png as in test_p2_aliasing_replay_matches_reference_digest, cut into chunk tasks: the
+    replay is recorded and applied by the task that holds the end of the stream."""
+    gold = json.load(open(os.path.join(GOLD, "resources.json")))["png"]["phoebus.png"]
+    data = open(os.path.join(GOLD, "resources", "phoebus.png"), "rb").read()
+    w, h = gold["width"], gold["height"]
+    at, z = 8, b""
+    while at + 8 <= len(data):
+        ln = int.from_bytes(data[at:at + 4], "big")
+        if data[at + 4:at + 8] == b"IDAT":
+            z += data[at + 8:at + 8 + ln]
+        at += 12 + ln
+    raw = z[2:-4]
+    est = 4 * w * h + h + 1
+    s0 = est - 772 + ((16 - (est & 15)) & 15)
+    outs, arena, offs = eb.emu_inflate(emu, [raw], [est], nw=eb.CHUNKED, chunk_bytes=2048, p2=[(s0, est)])
+    good, final, stream, r = outs[0]
+    assert good == 1 and final == est - 1
+    rgba = _emu_defilter(emu, stream, w, h, 6)
+    assert hashlib.sha256(rgba.tobytes()).hexdigest() == gold["rgba_sha256"]
+    print("phoebus: handed back", eb.last_split_retried, "blocks", r.n_blocks)

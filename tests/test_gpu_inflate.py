@@ -3,6 +3,7 @@
 Reference behaviour under test: src/inflate.c:786-1965 (inflate()), quirks Q1-Q15
 of SURVEY.md 8a.  Inputs are seeded; sizes are chosen so the oracle finishes in seconds.
 """
+import hashlib
 import random
 import zlib
 
@@ -49,7 +50,8 @@ def _payload(rng, n, kind):
 # wavefronts per stream: debig_inflate_kernel, debig_inflate_mw_kernel<2>, <4>, <8>, and the two
 # mixed modes (large streams 4-wide beside small ones 1- / 2-wide, include/debig_hip.h)
 # 0x10 = DEBIG_WAVES_SPLIT: the scan + LZ77 kernel pair (what the library picks for n > 1024)
-WIDTHS = (1, 2, 4, 8, 0x41, 0x42, 0x10)
+# 0x20 = DEBIG_WAVES_CHUNKED: large streams cut into chunk tasks at block headers
+WIDTHS = (1, 2, 4, 8, 0x41, 0x42, 0x10, 0x20)
 
 
 def _check(oracle, gpu_device, raws, caps, widths=WIDTHS, **kw):
@@ -272,6 +274,46 @@ def test_p2_aliasing_replay_every_width(gpu_device):
     for width in WIDTHS[1:]:
         for i, n in enumerate(names):
             assert got[width][i] == got[1][i], (width, n)
+
+
+def test_chunked_path_against_the_workgroup_path(gpu_device):
+    """DEBIG_WAVES_CHUNKED on streams of many chunk tasks (8 MiB image rows and text, the library's
+    own chunk size), intact and damaged (a flipped bit early, in the middle, near the end; a
+    truncated stream; a recipient one byte short): status, size and every byte must equal what
+    debig_inflate_mw_kernel<8> -- pinned to the oracle by the other tests -- returns."""
+    import random
+
+    rng = random.Random(77)
+    pairs = workload.make_streams("png", 3, 8 << 20) + workload.make_streams("dynamic", 3, 8 << 20)
+    raws, caps = [], []
+    for raw, plain in pairs:
+        raw = bytes(raw)
+        raws.append(raw); caps.append(len(plain))
+        for pos in (rng.randrange(50, 2000), len(raw) // 2 + rng.randrange(1000), len(raw) - rng.randrange(100, 3000)):
+            bad = bytearray(raw)
+            bad[pos] ^= 1 << rng.randrange(8)
+            raws.append(bytes(bad)); caps.append(len(plain) + 4096)
+    raws.append(raws[0][:len(raws[0]) * 2 // 3]); caps.append(caps[0])
+    raws.append(raws[0]); caps.append(caps[0] - 1)
+    b = DeviceBatch.from_streams(raws, caps, device=gpu_device, out_skew=3)
+    got = {}
+    for width in (8, 0x20):
+        b.d_out.zero_()
+        b.d_results.zero_()
+        b.launch(waves_per_stream=width)
+        res = b.results()
+        host = b.outputs_host()
+        rows = []
+        for i in range(len(raws)):
+            off, cap = int(b.streams_host[i]["out_off"]), int(b.streams_host[i]["out_cap"])
+            assert not host[off + cap:off + cap + 32].any(), (width, i)
+            n = int(res[i]["final_size"]) if res[i]["final_set"] else 0
+            rows.append((int(res[i]["good"]), int(res[i]["status"]), int(res[i]["final_set"]), n,
+                         hashlib.sha256(host[off:off + n].tobytes()).hexdigest()))
+        got[width] = rows
+    assert got[8][0][0] == 1 and got[8][4][0] == 1  # the intact ones decode
+    for i, (a, c) in enumerate(zip(got[8], got[0x20])):
+        assert a == c, (i, a, c)
 
 
 def test_invalid_width_is_rejected(gpu_device):
