@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json metric: decompressed GB/s + fraction of the HBM roofline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg4|cfg5]
 
 --config cfg2 (default; BASELINE config 2 = configs[1], SURVEY.md 8d "cfg2"): per GPU 4096
   fixed-Huffman streams + 4096 stored-block streams, every stream inflating to one 64 KiB
@@ -11,6 +11,10 @@
   1 MiB (text-like payload, dynamic Huffman, ratio about 2.5:1), member i -> GPU i mod N.
   Strong scaling: the total is fixed.  The payload bytes are inflated by the same kernel; the
   CRC-32 trailer of every member is verified on the GPU outside the timed region.
+
+--config cfg4 (BASELINE config 4 = configs[3]): per GPU --images (default 32: 256 images on 8 GPUs)
+  PNG files of 8192 x 8192 RGBA, every row Paeth-filtered, IDAT ratio about 3:1, 4 distinct seeds
+  cycled; a step is inflate + de-filter (decode_png's hot path) and `value` is GB/s of RGBA.  Weak.
 
 One "step" = one pass of the hot path (the batched inflate through the C-ABI,
 include/debig_hip.h) over this rank's whole shard, inputs already resident in HBM.
@@ -52,7 +56,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg5"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg4", "cfg5"])
+    ap.add_argument("--images", type=int, default=32, help="cfg4: PNG images per rank")
+    ap.add_argument("--side", type=int, default=8192, help="cfg4: image width and height")
     ap.add_argument("--streams", type=int, default=STREAMS_PER_KIND, help="cfg2: streams per kind per rank")
     ap.add_argument("--members", type=int, default=CFG5_MEMBERS, help="cfg5: gzip members in the whole job")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -262,9 +268,10 @@ def main():
 
     ncpu = max(1, min(16, (os.cpu_count() or 8) // max(1, min(world, 8))))
     cfg5 = args.config == "cfg5"
+    cfg4 = args.config == "cfg4"
 
     # ---- shard map: rank 0 builds it, RCCL broadcasts it (the only collective on the path)
-    n_units = args.members if cfg5 else world * args.streams
+    n_units = args.members if cfg5 else world * (args.images if cfg4 else args.streams)
     if world > 1:
         smap = shard.broadcast_shard_map(n_units, coll_dev, dist)
         mine = shard.my_streams(smap, rank)  # global ids of this rank's units, in local order
@@ -272,7 +279,40 @@ def main():
         mine = np.arange(n_units, dtype=np.int64)  # one rank owns everything; no GPU call yet (see below)
 
     kinds = {}
-    if not cfg5:
+    if cfg4:
+        # ---- cfg4: image g has seed 9000 + (g mod 4); this rank's images resident in HBM as one batch
+        from debigulator_amd.png_device import DevicePngBatch, split_png
+
+        seeds = sorted({int(g) % 4 for g in mine})
+        with ThreadPoolExecutor(min(4, ncpu)) as ex:
+            made = dict(zip(seeds, ex.map(lambda sd: workload.make_png(9000 + sd, args.side, args.side, ct=6, ftype=4,
+                                                                       noise=workload.CFG4_NOISE, enc="dynamic",
+                                                                       idat_chunk=65536), seeds)))
+        pngs = [made[int(g) % 4][0] for g in mine]
+        it0 = split_png(pngs[0])
+        est0 = 4 * args.side * args.side + args.side + 1
+        samples = {"png_idat_stream": [(it0["raw"], est0, est0 - 1)]}
+        sample_label = (f"inflate() of ONE image's IDAT stream ({len(it0['raw']) / 1e6:.0f} MB -> {(est0 - 1) / 1e6:.0f} MB of "
+                        f"filtered rows); the reference's de-filter loops are not in this number")
+        cpu_line = run_cpu_baseline(args, world, samples, sample_label)
+        torch.cuda.set_device(local_rank)
+        pbatch = DevicePngBatch(pngs, device=dev)
+        batch = pbatch  # .launch() = inflate + de-filter
+        c_bytes = pbatch.c_bytes
+        d_bytes = pbatch.rgba_bytes
+        unit_bytes = 4 * args.side * args.side
+
+        def verify():
+            res, ires = pbatch.results()
+            assert (res["good"] == 1).all() and (ires["good"] == 1).all(), "an image failed"
+            for i in sorted({0, 1 % len(pngs), 2 % len(pngs), 3 % len(pngs), len(pngs) - 1}):
+                want = np.asarray(made[int(mine[i]) % 4][1]).reshape(-1)
+                assert np.array_equal(pbatch.rgba(i), want), f"image {i} differs from the generator's pixels"
+            return res
+
+        workload_name = (f"cfg4: per GPU {len(pngs)} PNG images {args.side}x{args.side} RGBA, all rows Paeth, IDAT ratio "
+                         f"about 3:1, seeds 9000 + (i mod 4); one step = inflate + de-filter of the whole batch")
+    elif not cfg5:
         # ---- cfg2: this rank's shard, synthesised deterministically, parked in HBM as ONE batch:
         # the long-running Huffman streams first, the stored ones behind them
         assert len(mine) == args.streams
@@ -411,18 +451,27 @@ def main():
                     "avg_step_ms": ms, "decompressed_GBps": d / ms / 1e6, "launches_per_step": launches}
 
         split = len(res) > 1024  # include/debig_hip.h: what the library picks from the batch size
+        if cfg4:
+            # inflate reads C and writes the filtered rows S; the de-filter reads S and writes the pixels P
+            s_bytes = pbatch.s_bytes
+            what = ("one step = inflate of the IDAT streams (chunk-parallel path, inflate_chunk_kernel.inc: 11 small "
+                    "launches per stream group) + debig_png_defilter_kernel; algorithmic bytes C + 2 S + P")
+            rl = roof(c_bytes + 2 * s_bytes, d_bytes, step_ms, what, None)
+            rl["decompressed_GBps"] = d_bytes / step_ms / 1e6
         what = ("one step = debig_split_plan_kernel + debig_scan_kernel + debig_lz_kernel (+ debig_inflate_kernel for "
                 "streams handed back: none here), whole batch on rank 0" if split else
                 "one step = one debig_inflate(_mw)_kernel launch, whole batch on rank 0")
         lps = 4 if split else 1
-        rl = roof(c_bytes, d_bytes, step_ms, what, lps)
-        if not cfg5:
+        if not cfg4:
+            rl = roof(c_bytes, d_bytes, step_ms, what, lps)
+        if not cfg5 and not cfg4:
             tr, src = pmc_traffic(digest, args.streams / STREAMS_PER_KIND)
             rl["traffic"] = tr
             if src:
                 rl["traffic_source"] = src
         line = {
-            "metric": "decompressed GB/s (whole node) + % HBM roofline, bit-exact vs reference",
+            "metric": ("decoded RGBA GB/s (whole node) + % HBM roofline, bit-exact vs reference" if cfg4 else
+                       "decompressed GB/s (whole node) + % HBM roofline, bit-exact vs reference"),
             "value": value,
             "unit": "GB/s",
             "n_gpus": world,
@@ -441,7 +490,9 @@ def main():
                 "decompressed_bytes_job": job_d,
                 "compressed_bytes_job": job_c,
                 "ratio": job_d / job_c,
-                "bit_exact_checked": ("every member's size/good flag + CRC-32 (on the GPU), 3 members byte for byte"
+                "bit_exact_checked": ("every image's good flags; images 0-3 and the last byte for byte against the "
+                                      "generator's pixels" if cfg4 else
+                                      "every member's size/good flag + CRC-32 (on the GPU), 3 members byte for byte"
                                       if cfg5 else f"{min(args.verify, args.streams)} streams per kind byte for byte "
                                       f"+ all sizes/good flags"),
             },
