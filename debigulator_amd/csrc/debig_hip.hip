@@ -211,6 +211,8 @@ static int launch_split(hipStream_t s, const void *d_in, void *d_out, const debi
 // no host synchronisation; sizes live in device memory, so every grid is laid out for the number of
 // chunk tasks the workspace could hold and surplus workgroups leave at once.  Returns 0, a
 // hipError_t, or -1 when the workspace is too small to try.
+static int launch_inflate(uint32_t width, uint32_t cls, hipStream_t s, const void *d_in, void *d_out,
+                          const debig_stream *d_streams, debig_result *d_results, uint32_t n, const FixedTabs *tabs);
 static uint32_t chunk_bytes_override()
 {
     // DEBIG_CHUNK_BYTES: compressed bytes per chunk task (default: by batch size, 32..256 KiB)
@@ -231,9 +233,11 @@ static int launch_chunked(hipStream_t s, const void *d_in, void *d_out, const de
     uint8_t *ws = (uint8_t *)ws_;
     const uint8_t *in = (const uint8_t *)d_in;
     uint8_t *out = (uint8_t *)d_out;
+    // what is handed back: one workgroup per stream, as wide as the batch size allows
+    const uint32_t retry_w = n <= 256u ? 8u : n <= 512u ? 4u : n <= 1024u ? 2u : 1u;
     hipLaunchKernelGGL(debig_ck_plan_kernel, dim3(1), dim3(1024), 0, s, d_streams, n, ws, ws_bytes, mt, chunk_bytes_override());
-    hipLaunchKernelGGL(debig_ck_find_kernel, dim3(mt), dim3(64), 0, s, in, d_streams, n, ws, mt | (getenv("CKDBG") ? (uint32_t)atoi(getenv("CKDBG")) << 30 : 0u));
-    hipLaunchKernelGGL(debig_ck_bounds_kernel, dim3((n + 63u) / 64u), dim3(64), 0, s, n, ws);
+    hipLaunchKernelGGL(debig_ck_find_kernel, dim3(mt), dim3(64), 0, s, in, d_streams, n, ws, mt);
+    hipLaunchKernelGGL(debig_ck_bounds_kernel, dim3((n + 63u) / 64u), dim3(64), 0, s, d_streams, n, ws, retry_w > 1u ? 1u : 0u);
     hipLaunchKernelGGL(debig_ck_carve_kernel, dim3(1), dim3(1024), 0, s, d_streams, n, ws, mt);
     hipLaunchKernelGGL(debig_ck_scan_kernel, dim3(mt), dim3(64), 0, s, in, d_streams, n, (const uint32_t *)tabs->scan, ws, mt);
     hipLaunchKernelGGL(debig_ck_chain_kernel, dim3((n + 63u) / 64u), dim3(64), 0, s, d_streams, n, ws, mt);
@@ -242,9 +246,7 @@ static int launch_chunked(hipStream_t s, const void *d_in, void *d_out, const de
     hipLaunchKernelGGL(debig_ck_window_kernel, dim3(n), dim3(CK_WIN_THREADS), 0, s, (const uint8_t *)out, d_streams, n, ws, mt);
     hipLaunchKernelGGL(debig_ck_translate_kernel, dim3(mt * CK_TR_PARTS), dim3(CK_TR_THREADS), 0, s, out, d_streams, n, ws, mt);
     hipLaunchKernelGGL(debig_ck_finish_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, n, (const uint8_t *)ws, d_results);
-    hipLaunchKernelGGL(debig_inflate_kernel, dim3(n), dim3(64), 0, s, in, out, d_streams, d_results, n, tabs->one,
-                       DEBIG_CLASS_RETRY);
-    return (int)hipGetLastError();
+    return launch_inflate(retry_w, DEBIG_CLASS_RETRY, s, d_in, d_out, d_streams, d_results, n, tabs);
 }
 
 static int launch_inflate(uint32_t width, uint32_t cls, hipStream_t s, const void *d_in, void *d_out,

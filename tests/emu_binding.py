@@ -40,7 +40,7 @@ def load_emu(asan=False):
                                           C.POINTER(C.c_uint32)]
     L.emu_inflate_chunked_batch.restype = C.c_int
     L.emu_inflate_chunked_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
-                                            C.c_uint32, C.POINTER(C.c_uint32)]
+                                            C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     return L
 
 
@@ -79,7 +79,7 @@ def layout_batch(raws, caps, in_misalign=0, out_misalign=0, p2=None, flags=0):
     return in_arena, out_arena, streams, results, offs
 
 
-def emu_inflate(L, raws, caps, grid=0, nw=1, classes=None, ws_bytes=None, chunk_bytes=4096, **kw):
+def emu_inflate(L, raws, caps, grid=0, nw=1, classes=None, ws_bytes=None, chunk_bytes=4096, retry_width=1, **kw):
     """nw = 1: debig_inflate_kernel; nw = 2 / 4: debig_inflate_mw_kernel<nw> (one stream per
     workgroup of nw wavefronts).  classes = [(nw, cls), ...]: one launch per entry, each
     restricted to a stream class (1 small, 2 large), like the shim's mixed-width mode."""
@@ -104,7 +104,7 @@ def emu_inflate(L, raws, caps, grid=0, nw=1, classes=None, ws_bytes=None, chunk_
                         3 * sum(min(c, 1032 * len(r)) for r, c in zip(raws, caps)))
         nr = C.c_uint32(0)
         rc = L.emu_inflate_chunked_batch(in_arena.ctypes.data, out_arena.ctypes.data, streams, results, len(raws),
-                                         ws_bytes, chunk_bytes, C.byref(nr))
+                                         ws_bytes, chunk_bytes, retry_width, C.byref(nr))
         last_split_retried = nr.value
     elif nw == 1:
         rc = L.emu_inflate_batch(in_arena.ctypes.data, out_arena.ctypes.data, streams, results, len(raws), grid)

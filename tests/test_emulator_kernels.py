@@ -458,35 +458,40 @@ def test_resolve_idle_bound_is_reported_not_silent(emu, oracle):
 
 def test_kernels_under_address_sanitizer():
     """SURVEY 5 'sanitizers on the CPU build': the same kernel source under ASan + UBSan
-    (tools/simt_emu/libdebig_emu_asan.so) on a small mixed batch, every kernel width.  Runs in a
-    child process (the sanitizer runtime has to be loaded first)."""
+    (tools/simt_emu/libdebig_emu_asan.so).  Runs in a child process (the sanitizer runtime has to
+    be loaded first).  The instrumented fibers are slow (a 700-byte stream takes seconds), so the
+    default run is small: the one-kernel path and the chunk-parallel path (which runs the scan and
+    LZ77 bodies of the throughput path and every chunk kernel) on a stored and a dynamic stream cut
+    into 1 KiB chunks.  DEBIG_ASAN_FULL=1: every width, more and larger streams (about 15 minutes)."""
     import subprocess
     import sys
 
+    full = os.environ.get("DEBIG_ASAN_FULL") == "1"
     code = r'''
 import sys, json, os, hashlib
 sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, %(root)r)
 import emu_binding as eb
 from debigulator_amd import workload
 L = eb.load_emu(asan=True)
-items = json.load(open(os.path.join(%(root)r, "tests", "golden", "kat.json")))
-items = items[:6]
+full = %(full)r
+items = json.load(open(os.path.join(%(root)r, "tests", "golden", "kat.json")))[:6 if full else 0]
 raws = [bytes.fromhex(k["raw_hex"]) for k in items]; caps = [k["recipient_size"] for k in items]
-for kind in ("stored", "dynamic"):
-    raw, plain = workload.make_stream(kind, 3, 5000)
-    raws.append(raw); caps.append(max(5001, len(raw))); items.append({"good": 1, "final": 5000, "plain": plain.tobytes()})
-for nw in (1, 4, eb.SPLIT):
-    outs, arena, offs = eb.emu_inflate(L, raws, caps, nw=nw, in_misalign=1, out_misalign=3)
+for kind, size in ((("stored", 5000), ("dynamic", 5000), ("fixed", 3000)) if full else (("stored", 300), ("dynamic", 700))):
+    raw, plain = workload.make_stream(kind, 3, size)
+    raws.append(raw); caps.append(max(size + 1, len(raw))); items.append({"good": 1, "final": size, "plain": plain.tobytes()})
+for nw in ((1, 4, eb.SPLIT, eb.CHUNKED) if full else (1, eb.CHUNKED)):
+    outs, arena, offs = eb.emu_inflate(L, raws, caps, nw=nw, in_misalign=1, out_misalign=3, chunk_bytes=1024)
+    if nw == eb.CHUNKED: assert eb.last_split_retried == 0
     for k, (good, final, out, r) in zip(items, outs):
         assert good == k["good"] and final == k["final"], (nw, k.get("name"))
         if "plain" in k: assert out == k["plain"]
         elif k.get("out_hex") is not None: assert out.hex() == k["out_hex"]
 print("asan ok")
-''' % {"root": ROOT}
+''' % {"root": ROOT, "full": full}
     import ctypes.util  # noqa: F401
     asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0")
-    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=3000 if full else 600)
     assert p.returncode == 0 and "asan ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
@@ -647,7 +652,8 @@ def test_chunked_path_false_header_and_damage_go_to_the_one_kernel_path(emu, ora
         caps.append(len(text) + 100)
     raws.append(good_raw[:len(good_raw) // 2])  # truncated: no final block
     caps.append(len(text))
-    outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=eb.CHUNKED, chunk_bytes=4096)
+    # what is handed back goes to a workgroup of 4 wavefronts here (the shim's choice for small batches)
+    outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=eb.CHUNKED, chunk_bytes=4096, retry_width=4)
     assert outs[0][0] == 1 and outs[0][2] == want
     assert eb.last_split_retried >= 2
     for raw, cap, (good, final, out, r) in zip(raws, caps, outs):
@@ -664,6 +670,15 @@ def test_chunked_path_small_workspace_hands_everything_back(emu, oracle):
     caps = [len(text), 50000]
     outs, _, _ = eb.emu_inflate(emu, raws, caps, nw=eb.CHUNKED, chunk_bytes=4096, ws_bytes=300000)
     assert eb.last_split_retried >= 1
+    for raw, cap, (good, final, out, r) in zip(raws, caps, outs):
+        assert (good, final, out) == oracle.inflate(raw, cap)[:3]
+    # with workgroups behind it the path also hands back a large stream that is one task (fixed blocks only)
+    big = _text(rng, 700000)
+    raws = [_raw(big, 6, zlib.Z_FIXED), _raw(text, 6)]
+    assert len(raws[0]) >= 256 << 10
+    caps = [len(big), len(text)]
+    outs, _, _ = eb.emu_inflate(emu, raws, caps, nw=eb.CHUNKED, chunk_bytes=8192, retry_width=4)
+    assert eb.last_split_retried == 1
     for raw, cap, (good, final, out, r) in zip(raws, caps, outs):
         assert (good, final, out) == oracle.inflate(raw, cap)[:3]
 

@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "hip_emu.h"
+/* the single-workgroup planning kernels take any power-of-two block size: 64 fibers instead of 1024 */
+#define EMU_PLAN_THREADS 64
 #include "../../include/debig_hip.h"
 #include "../../debigulator_amd/csrc/inflate_kernel.inc"
 #include "../../debigulator_amd/csrc/inflate_mw_kernel.inc"
@@ -89,7 +91,7 @@ extern "C" int emu_inflate_split_batch(const void *in, void *out, const debig_st
     debig_ws_slot *slots = (debig_ws_slot *)ws;
     debig_ws_rec *recs = (debig_ws_rec *)(ws + slots_bytes);
     uint32_t *rows = (uint32_t *)(ws + slots_bytes + recs_bytes);
-    EMU_LAUNCH(debig_split_plan_kernel, 1, 1024, streams, n, slots, total_rows, total_recs);
+    EMU_LAUNCH(debig_split_plan_kernel, 1, EMU_PLAN_THREADS, streams, n, slots, total_rows, total_recs);
     EMU_LAUNCH(debig_scan_kernel, n, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
     EMU_LAUNCH(debig_lz_kernel, n, 64, (uint8_t *)out, streams, results, n, (const debig_ws_slot *)slots,
                (const debig_ws_rec *)recs, (const uint32_t *)rows);
@@ -104,7 +106,8 @@ extern "C" int emu_inflate_split_batch(const void *in, void *out, const debig_st
 // the chunk-parallel path for large streams (inflate_chunk_kernel.inc), kernel by kernel as the
 // shim launches them; n_retried: streams handed to debig_inflate_kernel
 extern "C" int emu_inflate_chunked_batch(const void *in, void *out, const debig_stream *streams, debig_result *results,
-                                         uint32_t n, uint64_t ws_bytes, uint32_t chunk_bytes, uint32_t *n_retried)
+                                         uint32_t n, uint64_t ws_bytes, uint32_t chunk_bytes, uint32_t retry_width,
+                                         uint32_t *n_retried)
 {
     static uint32_t *ft = nullptr;
     if (!ft) {
@@ -120,13 +123,13 @@ extern "C" int emu_inflate_chunked_batch(const void *in, void *out, const debig_
     if (mt == 0) return -1;
     uint8_t *ws = (uint8_t *)aligned_alloc(256, (ws_bytes + 255) / 256 * 256);
     memset(ws, 0xEE, ws_bytes); /* poison: nothing may be read before it is written */
-    EMU_LAUNCH(debig_ck_plan_kernel, 1, 1024, streams, n, ws, ws_bytes, mt, chunk_bytes);
+    EMU_LAUNCH(debig_ck_plan_kernel, 1, EMU_PLAN_THREADS, streams, n, ws, ws_bytes, mt, chunk_bytes);
     EMU_LAUNCH(debig_ck_find_kernel, mt, 64, (const uint8_t *)in, streams, n, ws, mt);
-    EMU_LAUNCH(debig_ck_bounds_kernel, (n + 63) / 64, 64, n, ws);
-    EMU_LAUNCH(debig_ck_carve_kernel, 1, 1024, streams, n, ws, mt);
+    EMU_LAUNCH(debig_ck_bounds_kernel, (n + 63) / 64, 64, streams, n, ws, retry_width > 1 ? 1u : 0u);
+    EMU_LAUNCH(debig_ck_carve_kernel, 1, EMU_PLAN_THREADS, streams, n, ws, mt);
     EMU_LAUNCH(debig_ck_scan_kernel, mt, 64, (const uint8_t *)in, streams, n, (const uint32_t *)fts, ws, mt);
     EMU_LAUNCH(debig_ck_chain_kernel, (n + 63) / 64, 64, streams, n, ws, mt);
-    EMU_LAUNCH(debig_ck_place_kernel, 1, 1024, n, ws);
+    EMU_LAUNCH(debig_ck_place_kernel, 1, EMU_PLAN_THREADS, n, ws);
     EMU_LAUNCH(debig_ck_lz_kernel, 2 * mt, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, ws, mt);
     EMU_LAUNCH(debig_ck_window_kernel, n, CK_WIN_THREADS, (const uint8_t *)out, streams, n, ws, mt);
     EMU_LAUNCH(debig_ck_translate_kernel, mt * CK_TR_PARTS, CK_TR_THREADS, (uint8_t *)out, streams, n, ws, mt);
@@ -151,6 +154,14 @@ extern "C" int emu_inflate_chunked_batch(const void *in, void *out, const debig_
             }
         }
     }
+    if (retry_width > 1) {
+        static uint32_t *ftm = nullptr;
+        if (!ftm) {
+            ftm = (uint32_t *)calloc(1, sizeof(decltype(WaveLdsT<2>::t)));
+            EMU_LAUNCH(debig_fixed_tables_kernel<2>, 1, 64, ftm);
+        }
+        EMU_LAUNCH(debig_inflate_mw_kernel<4>, n, 256, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ftm, DEBIG_CLASS_RETRY);
+    } else
     EMU_LAUNCH(debig_inflate_kernel, n, 64, (const uint8_t *)in, (uint8_t *)out, streams, results, n, ft, DEBIG_CLASS_RETRY);
     free(ws);
     return 0;
