@@ -239,7 +239,9 @@ static int launch_chunked(hipStream_t s, const void *d_in, void *d_out, const de
     hipLaunchKernelGGL(debig_ck_find_kernel, dim3(mt), dim3(64), 0, s, in, d_streams, n, ws, mt);
     hipLaunchKernelGGL(debig_ck_bounds_kernel, dim3((n + 63u) / 64u), dim3(64), 0, s, d_streams, n, ws, retry_w > 1u ? 1u : 0u);
     hipLaunchKernelGGL(debig_ck_carve_kernel, dim3(1), dim3(1024), 0, s, d_streams, n, ws, mt);
-    hipLaunchKernelGGL(debig_ck_scan_kernel, dim3(mt), dim3(64), 0, s, in, d_streams, n, (const uint32_t *)tabs->scan, ws, mt);
+    hipLaunchKernelGGL(debig_ck_scan_kernel, dim3(mt), dim3(64), 0, s, in, d_streams, n, (const uint32_t *)tabs->scan, ws, mt, 0u);
+    hipLaunchKernelGGL(debig_ck_repair_kernel, dim3((n + 63u) / 64u), dim3(64), 0, s, n, ws, mt);
+    hipLaunchKernelGGL(debig_ck_scan_kernel, dim3(mt), dim3(64), 0, s, in, d_streams, n, (const uint32_t *)tabs->scan, ws, mt, 1u);
     hipLaunchKernelGGL(debig_ck_chain_kernel, dim3((n + 63u) / 64u), dim3(64), 0, s, d_streams, n, ws, mt);
     hipLaunchKernelGGL(debig_ck_place_kernel, dim3(1), dim3(1024), 0, s, n, ws);
     hipLaunchKernelGGL(debig_ck_lz_kernel, dim3(2u * mt), dim3(64), 0, s, in, out, d_streams, n, ws, mt);

@@ -627,11 +627,12 @@ def test_chunked_path_cuts_large_streams_at_block_headers(emu, oracle):
         assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
 
 
-def test_chunked_path_false_header_and_damage_go_to_the_one_kernel_path(emu, oracle):
+def test_chunked_path_false_header_is_repaired_and_damage_goes_to_the_one_kernel_path(emu, oracle):
     """A byte-aligned copy of a real dynamic block inside a STORED block is what the block finder
-    looks for but not a block boundary: the chain check must refuse the stream (the one-kernel path
-    decodes it).  Damaged streams: whatever the chunk tasks make of the bytes behind the damage,
-    the result is the oracle's."""
+    looks for but not a block boundary: the scan of the task before it runs past it to the next
+    real boundary, the repair kernel restarts the false task there, and the stream still decodes in
+    chunk tasks.  Damaged streams: whatever the chunk tasks make of the bytes behind the damage,
+    the result is the oracle's (from the one-kernel path)."""
     rng = random.Random(12)
     text = _text(rng, 200000)
     decoy = _raw(text[:30000], 6)[:6000]          # starts with a dynamic block header at bit 0
@@ -643,6 +644,24 @@ def test_chunked_path_false_header_and_damage_go_to_the_one_kernel_path(emu, ora
     trap = a + stored + tail
     want = text[:60000] + decoy + text[60000:140000]
     assert zlib.decompress(trap, -15) == want
+    # a second trap: a short decoy right behind the start of a 4 KiB search range, so that the real
+    # boundary behind it lies in the SAME range and no task finds it: the false task is restarted
+    # there and scanned again (the first trap's false task is simply emptied)
+    trap2 = want2 = None
+    for cut in range(60000, 64096, 7):
+        c3 = zlib.compressobj(6, zlib.DEFLATED, -15)
+        a2 = c3.compress(text[:cut]) + c3.flush(zlib.Z_FULL_FLUSH)
+        if (len(a2) + 5) % 4096 < 900:
+            d2 = decoy[:1500]
+            st2 = b"\x00" + len(d2).to_bytes(2, "little") + (len(d2) ^ 0xffff).to_bytes(2, "little") + d2
+            c4 = zlib.compressobj(6, zlib.DEFLATED, -15)
+            trap2 = a2 + st2 + c4.compress(text[cut:cut + 80000]) + c4.flush()
+            want2 = text[:cut] + d2 + text[cut:cut + 80000]
+            break
+    assert trap2 is not None and zlib.decompress(trap2, -15) == want2
+    outs, _, _ = eb.emu_inflate(emu, [trap, trap2], [len(want) + 11, len(want2)], nw=eb.CHUNKED, chunk_bytes=4096)
+    assert eb.last_split_retried == 0
+    assert outs[0][0] == 1 and outs[0][2] == want and outs[1][0] == 1 and outs[1][2] == want2
     raws, caps = [trap], [len(want) + 11]
     good_raw = _raw(text, 6)
     for pos in (100, len(good_raw) // 3, len(good_raw) // 2, len(good_raw) - 3000):
@@ -655,7 +674,7 @@ def test_chunked_path_false_header_and_damage_go_to_the_one_kernel_path(emu, ora
     # what is handed back goes to a workgroup of 4 wavefronts here (the shim's choice for small batches)
     outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=eb.CHUNKED, chunk_bytes=4096, retry_width=4)
     assert outs[0][0] == 1 and outs[0][2] == want
-    assert eb.last_split_retried >= 2
+    assert 1 <= eb.last_split_retried <= len(raws) - 1  # the early flip at least; a flipped literal still decodes
     for raw, cap, (good, final, out, r) in zip(raws, caps, outs):
         eg, ef, eo, st = oracle.inflate(raw, cap, want_stats=True)
         if st.ub_flags & (0x10 | 0x02):

@@ -369,3 +369,29 @@ def test_inflate_batch_multi_one_device_and_staging(api, oracle):
         else:
             assert finals[i] == f and outs[i][:f].tobytes() == o, i
     assert L.debig_inflate_batch_multi(out_ptrs, capsa, finals, in_ptrs, in_sizes, goods, n, 9) != 0  # no such device
+
+
+def test_large_streams_take_the_chunk_parallel_path_through_the_c_calls(api, monkeypatch):
+    """Few streams with 1 MiB of input or more on average: the C host layer (csrc/host/debig_ctx.c)
+    picks DEBIG_WAVES_CHUNKED and passes the batch in groups of streams that fit its workspace
+    cap; with DEBIG_CHUNKED_WS_MB=48 the five streams below need several groups.  decode_png() of a
+    1024 x 1024 all-Paeth image goes the same way.  Everything must come back exact."""
+    pairs = workload.make_streams("dynamic", 3, 3 << 20) + workload.make_streams("png", 2, 4 << 20)
+    assert sum(len(p[0]) for p in pairs) >= len(pairs) << 20
+    for cap_mb in (None, "48"):
+        if cap_mb is None:
+            monkeypatch.delenv("DEBIG_CHUNKED_WS_MB", raising=False)
+        else:
+            monkeypatch.setenv("DEBIG_CHUNKED_WS_MB", cap_mb)
+        res = api.inflate_batch([p[0] for p in pairs], [len(p[1]) for p in pairs])
+        for i, ((good, final, out), (_, plain)) in enumerate(zip(res, pairs)):
+            assert good == 1 and final == len(plain), (cap_mb, i)
+            assert out == plain.tobytes(), (cap_mb, i)
+    monkeypatch.delenv("DEBIG_CHUNKED_WS_MB", raising=False)
+    png, pix = workload.make_png(7300, 1024, 1024, ct=6, ftype=4, noise=workload.CFG4_NOISE, enc="dynamic")
+    assert len(png) >= 1 << 20
+    good, rgba = api.decode_png(png)
+    assert good == 1 and np.array_equal(rgba.reshape(1024, 4096), pix)
+    outs = api.decode_png_batch([png, png, png])
+    for good, rgba in outs:
+        assert good == 1 and np.array_equal(np.asarray(rgba).reshape(1024, 4096), pix)

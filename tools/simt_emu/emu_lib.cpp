@@ -127,7 +127,9 @@ extern "C" int emu_inflate_chunked_batch(const void *in, void *out, const debig_
     EMU_LAUNCH(debig_ck_find_kernel, mt, 64, (const uint8_t *)in, streams, n, ws, mt);
     EMU_LAUNCH(debig_ck_bounds_kernel, (n + 63) / 64, 64, streams, n, ws, retry_width > 1 ? 1u : 0u);
     EMU_LAUNCH(debig_ck_carve_kernel, 1, EMU_PLAN_THREADS, streams, n, ws, mt);
-    EMU_LAUNCH(debig_ck_scan_kernel, mt, 64, (const uint8_t *)in, streams, n, (const uint32_t *)fts, ws, mt);
+    EMU_LAUNCH(debig_ck_scan_kernel, mt, 64, (const uint8_t *)in, streams, n, (const uint32_t *)fts, ws, mt, 0u);
+    EMU_LAUNCH(debig_ck_repair_kernel, (n + 63) / 64, 64, n, ws, mt);
+    EMU_LAUNCH(debig_ck_scan_kernel, mt, 64, (const uint8_t *)in, streams, n, (const uint32_t *)fts, ws, mt, 1u);
     EMU_LAUNCH(debig_ck_chain_kernel, (n + 63) / 64, 64, streams, n, ws, mt);
     EMU_LAUNCH(debig_ck_place_kernel, 1, EMU_PLAN_THREADS, n, ws);
     EMU_LAUNCH(debig_ck_lz_kernel, 2 * mt, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, ws, mt);
