@@ -454,7 +454,7 @@ def main():
         if cfg4:
             # inflate reads C and writes the filtered rows S; the de-filter reads S and writes the pixels P
             s_bytes = pbatch.s_bytes
-            what = ("one step = inflate of the IDAT streams (chunk-parallel path, inflate_chunk_kernel.inc: 11 small "
+            what = ("one step = inflate of the IDAT streams (chunk-parallel path, inflate_chunk_kernel.inc: 14 small "
                     "launches per stream group) + debig_png_defilter_kernel; algorithmic bytes C + 2 S + P")
             rl = roof(c_bytes + 2 * s_bytes, d_bytes, step_ms, what, None)
             rl["decompressed_GBps"] = d_bytes / step_ms / 1e6

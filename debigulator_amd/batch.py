@@ -67,6 +67,8 @@ def plan_batch(streams):
     lens = streams["in_len"].astype(np.int64)
     if 0 < n <= 1024 and int(lens.sum()) >= n << 20:  # few streams, >= 1 MiB of input each on average
         return None, N.WAVES_CHUNKED                   # debig_ctx.h: debig_pick_waves
+    if 1024 < n <= 16384 and int(lens.max()) >= 4 << 20:  # thousands of streams, a very large one among them
+        return None, N.WAVES_CHUNKED
     if n <= 512 or n > 1024:
         return None, 0
     order = np.lexsort((np.arange(n), -lens))

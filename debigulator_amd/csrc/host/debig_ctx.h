@@ -54,6 +54,7 @@ int debig_download_unpack(debig_ctx *c, const void *d_arena, uint8_t *const *dst
  * 8 wavefronts per stream, 5.5 ms in chunk tasks; config 3's 1024 sample PNGs (0.43 MB on
  * average) are 40 % slower in chunk tasks.  The line is drawn at 1 MiB of input per stream. */
 #define DEBIG_CHUNKED_MEAN_IN_BYTES (1u << 20)
+#define DEBIG_CHUNKED_LONGEST_IN_BYTES (4u << 20) /* n > 1024: one stream this long is enough */
 static inline uint32_t debig_pick_waves(const debig_stream *desc, uint32_t n)
 {
     if (n <= 1024u) {
@@ -65,8 +66,14 @@ static inline uint32_t debig_pick_waves(const debig_stream *desc, uint32_t n)
     if (n <= 512u) return 4u;
     if (n <= 1024u) return 2u;
     uint32_t n_large = 0;
-    for (uint32_t i = 0; i < n; i++)
+    uint64_t longest = 0;
+    for (uint32_t i = 0; i < n; i++) {
         n_large += desc[i].in_len >= DEBIG_LARGE_IN_BYTES || desc[i].out_cap >= DEBIG_LARGE_OUT_BYTES;
+        if (desc[i].in_len > longest) longest = desc[i].in_len;
+    }
+    /* thousands of streams and a very large one among them: chunk tasks for everything (a small
+     * stream is one task: the scan / LZ77 bodies of the throughput path) */
+    if (longest >= DEBIG_CHUNKED_LONGEST_IN_BYTES && n <= 16384u) return DEBIG_WAVES_CHUNKED;
     return (n_large != 0 && n_large <= 256u) ? DEBIG_WAVES_LARGE4_SMALL1 : DEBIG_WAVES_SPLIT;
 }
 

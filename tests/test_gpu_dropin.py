@@ -388,6 +388,17 @@ def test_large_streams_take_the_chunk_parallel_path_through_the_c_calls(api, mon
             assert good == 1 and final == len(plain), (cap_mb, i)
             assert out == plain.tobytes(), (cap_mb, i)
     monkeypatch.delenv("DEBIG_CHUNKED_WS_MB", raising=False)
+    # more than 1024 streams with a very large one among them: chunk tasks for the whole batch
+    small = workload.make_streams("dynamic", 16, 20000)
+    big = workload.make_streams("dynamic", 2, 12 << 20)
+    assert max(len(b[0]) for b in big) >= 4 << 20
+    mixed = [small[i % 16] for i in range(1100)]
+    mixed[3], mixed[1000] = big[0], big[1]
+    res = api.inflate_batch([p[0] for p in mixed], [len(p[1]) + 1 for p in mixed])
+    for i, ((good, final, out), (_, plain)) in enumerate(zip(res, mixed)):
+        assert good == 1 and final == len(plain), i
+        if i % 97 == 0 or i in (3, 1000):
+            assert out == plain.tobytes(), i
     png, pix = workload.make_png(7300, 1024, 1024, ct=6, ftype=4, noise=workload.CFG4_NOISE, enc="dynamic")
     assert len(png) >= 1 << 20
     good, rgba = api.decode_png(png)
