@@ -42,6 +42,7 @@ struct emu_dim3 { unsigned x, y, z; };
 
 struct emu_fiber {
     ucontext_t ctx;
+    void *sp; /* x86-64: saved stack pointer of the hand-written switch (no system calls) */
     char *stack;
     size_t stack_size;
     unsigned tid;
@@ -51,6 +52,7 @@ struct emu_fiber {
 
 struct emu_state {
     ucontext_t sched;
+    void *sched_sp; /* x86-64: the scheduler's saved stack pointer */
     std::vector<emu_fiber> fibers;
     unsigned cur;
     unsigned nthreads;
@@ -77,13 +79,25 @@ static emu_tid_proxy threadIdx __attribute__((unused));
 #define blockDim g_emu_blockDim
 #define gridDim g_emu_gridDim
 
+/* Fiber switch.  swapcontext() saves and restores the signal mask with two system calls per switch,
+ * which was most of the emulator's run time; on x86-64 a dozen instructions do (callee-saved
+ * registers, MXCSR and the x87 control word travel on the fiber's own stack). */
+#if defined(__x86_64__)
+extern "C" void emu_ctx_switch(void **from_sp, void *to_sp);
+static inline void emu_to_scheduler(emu_fiber &f) { emu_ctx_switch(&f.sp, g_emu.sched_sp); }
+static inline void emu_to_fiber(emu_fiber &f) { emu_ctx_switch(&g_emu.sched_sp, f.sp); }
+#else
+static inline void emu_to_scheduler(emu_fiber &f) { swapcontext(&f.ctx, &g_emu.sched); }
+static inline void emu_to_fiber(emu_fiber &f) { swapcontext(&g_emu.sched, &f.ctx); }
+#endif
+
 static inline void emu_yield()
 {
     emu_fiber &f = g_emu.fibers[g_emu.cur];
 #if EMU_ASAN
     __sanitizer_start_switch_fiber(&f.fake_stack, g_emu.sched.uc_stack.ss_sp, g_emu.sched.uc_stack.ss_size);
 #endif
-    swapcontext(&f.ctx, &g_emu.sched);
+    emu_to_scheduler(f);
 #if EMU_ASAN
     __sanitizer_finish_switch_fiber(f.fake_stack, nullptr, nullptr);
 #endif
