@@ -244,7 +244,7 @@ static int launch_chunked(hipStream_t s, const void *d_in, void *d_out, const de
     hipLaunchKernelGGL(debig_ck_scan_kernel, dim3(mt), dim3(64), 0, s, in, d_streams, n, (const uint32_t *)tabs->scan, ws, mt, 1u);
     hipLaunchKernelGGL(debig_ck_chain_kernel, dim3((n + 63u) / 64u), dim3(64), 0, s, d_streams, n, ws, mt);
     hipLaunchKernelGGL(debig_ck_place_kernel, dim3(1), dim3(1024), 0, s, n, ws);
-    hipLaunchKernelGGL(debig_ck_lz_kernel, dim3(2u * mt), dim3(64), 0, s, in, out, d_streams, n, ws, mt);
+    hipLaunchKernelGGL(debig_ck_lz_kernel, dim3(mt), dim3(64), 0, s, in, out, d_streams, n, ws, mt);
     hipLaunchKernelGGL(debig_ck_window_kernel, dim3(n), dim3(CK_WIN_THREADS), 0, s, (const uint8_t *)out, d_streams, n, ws, mt);
     hipLaunchKernelGGL(debig_ck_translate_kernel, dim3(mt * CK_TR_PARTS), dim3(CK_TR_THREADS), 0, s, out, d_streams, n, ws, mt);
     hipLaunchKernelGGL(debig_ck_finish_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, n, (const uint8_t *)ws, d_results);

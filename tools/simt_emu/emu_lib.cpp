@@ -132,7 +132,7 @@ extern "C" int emu_inflate_chunked_batch(const void *in, void *out, const debig_
     EMU_LAUNCH(debig_ck_scan_kernel, mt, 64, (const uint8_t *)in, streams, n, (const uint32_t *)fts, ws, mt, 1u);
     EMU_LAUNCH(debig_ck_chain_kernel, (n + 63) / 64, 64, streams, n, ws, mt);
     EMU_LAUNCH(debig_ck_place_kernel, 1, EMU_PLAN_THREADS, n, ws);
-    EMU_LAUNCH(debig_ck_lz_kernel, 2 * mt, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, ws, mt);
+    EMU_LAUNCH(debig_ck_lz_kernel, mt, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, ws, mt);
     EMU_LAUNCH(debig_ck_window_kernel, n, CK_WIN_THREADS, (const uint8_t *)out, streams, n, ws, mt);
     EMU_LAUNCH(debig_ck_translate_kernel, mt * CK_TR_PARTS, CK_TR_THREADS, (uint8_t *)out, streams, n, ws, mt);
     EMU_LAUNCH(debig_ck_finish_kernel, (n + 255) / 256, 256, n, (const uint8_t *)ws, results);
