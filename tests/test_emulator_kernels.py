@@ -719,3 +719,55 @@ def test_chunked_path_p2_aliasing_replay_in_the_last_task(emu):
     rgba = _emu_defilter(emu, stream, w, h, 6)
     assert hashlib.sha256(rgba.tobytes()).hexdigest() == gold["rgba_sha256"]
     print("phoebus: handed back", eb.last_split_retried, "blocks", r.n_blocks)
+
+
+@pytest.mark.parametrize("seed,chunk", [(21, 1024), (22, 2048), (23, 6144), (24, 1024), (25, 3072), (26, 4096), (27, 1536),
+                                        (28, 8192), (29, 1024), (30, 2048)])
+def test_chunked_path_random_streams_agree_with_oracle(emu, oracle, seed, chunk):
+    """Random block structures through chunk tasks of several sizes: text / noise / run mixtures,
+    every zlib level and strategy, sync and full flushes at random places, a third of the streams
+    damaged (flipped bit or cut short): status, size and bytes must be the oracle's."""
+    rng = random.Random(seed)
+    nprng = np.random.default_rng(seed)
+    raws, caps = [], []
+    for it in range(14):
+        parts = []
+        for _ in range(rng.randint(1, 5)):
+            kind = rng.random()
+            n = rng.randint(2000, 30000)
+            if kind < 0.5:
+                parts.append(_text(rng, n))
+            elif kind < 0.7:
+                parts.append(nprng.integers(0, 256, n, dtype=np.uint8).tobytes())
+            elif kind < 0.85:
+                parts.append(bytes([rng.randrange(256)]) * n)
+            else:
+                parts.append((bytes(rng.getrandbits(8) for _ in range(rng.randint(2, 40))) * (n // 2 + 1))[:n])
+        strat = rng.choice([zlib.Z_DEFAULT_STRATEGY] * 4 + [zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED])
+        c = zlib.compressobj(rng.choice([1, 3, 6, 9]), zlib.DEFLATED, -15, rng.choice([8, 9]), strat)
+        raw = b""
+        for p in parts:
+            raw += c.compress(p)
+            if rng.random() < 0.4:
+                raw += c.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH]))
+        raw += c.flush()
+        plain = b"".join(parts)
+        r = rng.random()
+        if r < 0.2 and len(raw) > 200:
+            bad = bytearray(raw)
+            bad[rng.randrange(len(bad))] ^= 1 << rng.randrange(8)
+            raw = bytes(bad)
+        elif r < 0.33 and len(raw) > 200:
+            raw = raw[:rng.randint(100, len(raw) - 1)]
+        raws.append(raw)
+        caps.append(max(len(plain) + rng.choice([0, 1, 100]), len(raw)))
+    outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=eb.CHUNKED, chunk_bytes=chunk, in_misalign=seed & 7,
+                                       out_misalign=seed % 5, retry_width=rng.choice([1, 4]))
+    for i, (raw, cap, (good, final, out, r)) in enumerate(zip(raws, caps, outs)):
+        eg, ef, eo, st = oracle.inflate(raw, cap, want_stats=True)
+        if st.ub_flags & (0x10 | 0x02):
+            continue
+        assert (good, final) == (eg, ef), (i, r.status)
+        assert out == eo, i
+    for (io, oo), cap in zip(offs, caps):
+        assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
