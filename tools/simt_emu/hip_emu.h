@@ -208,6 +208,7 @@ static inline unsigned long long emu___ballot(int pred)
 static inline int emu___any(int p) { return emu___ballot(p) != 0; }
 static inline int emu___all(int p) { return emu___ballot(!p) == 0; }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 static inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
