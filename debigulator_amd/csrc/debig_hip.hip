@@ -385,7 +385,8 @@ static uint32_t defilter_waves(uint32_t n)
         if (e && *e) env_val = (uint32_t)strtoul(e, nullptr, 0);
         env_read = 1;
     }
-    if (env_val == 1 || env_val == 2 || env_val == 4 || env_val == 8) return env_val;
+    if (env_val == 1 || env_val == 2 || env_val == 4 || env_val == 8 || env_val == 16) return env_val;
+    if (n <= 64u) return 16u; /* 32 images of 8192 x 8192: 52.5 -> 46.2 ms; from 128 images on 8 is as good */
     if (n <= 256u) return 8u;
     if (n <= 512u) return 4u;
     if (n <= 1024u) return 2u;
@@ -403,7 +404,10 @@ int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena
 #define DEFILTER_LAUNCH(W)                                                                              \
     hipLaunchKernelGGL(debig_png_defilter_kernel<W>, dim3(n), dim3(64 * W), 0, s, (const uint8_t *)d_streams_arena, \
                        (uint8_t *)d_rgba_arena, d_images, d_results, n)
-    if (nwd == 8) DEFILTER_LAUNCH(8);
+    if (nwd == 16)
+        hipLaunchKernelGGL((debig_png_defilter_kernel<16, 6>), dim3(n), dim3(1024), 0, s, (const uint8_t *)d_streams_arena,
+                           (uint8_t *)d_rgba_arena, d_images, d_results, n);
+    else if (nwd == 8) DEFILTER_LAUNCH(8);
     else if (nwd == 4) DEFILTER_LAUNCH(4);
     else if (nwd == 2) DEFILTER_LAUNCH(2);
     else DEFILTER_LAUNCH(1);

@@ -334,7 +334,7 @@ def test_defilter_kernel_group_and_band_edges(emu, ct):
         assert np.array_equal(rgba, exp), (ct, w, h)
 
 
-@pytest.mark.parametrize("nwd", [2, 4, 8])
+@pytest.mark.parametrize("nwd", [2, 4, 8, 16])
 def test_defilter_kernel_several_wavefronts_per_image(emu, nwd):
     """debig_png_defilter_kernel<NWD>: the bands of one image pipelined through NWD wavefronts (band
     k+1 runs about 80 groups behind band k and takes the row above it from the output).  Images

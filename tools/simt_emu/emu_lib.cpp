@@ -172,7 +172,9 @@ extern "C" int emu_inflate_chunked_batch(const void *in, void *out, const debig_
 extern "C" int emu_png_defilter_batch_w(const void *streams_arena, void *rgba_arena, const debig_png_image *images,
                                         debig_png_result *results, uint32_t n, uint32_t nwd)
 {
-    if (nwd == 8)
+    if (nwd == 16)
+        EMU_LAUNCH((debig_png_defilter_kernel<16, 6>), n, 1024, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images, results, n);
+    else if (nwd == 8)
         EMU_LAUNCH(debig_png_defilter_kernel<8>, n, 512, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images, results, n);
     else if (nwd == 4)
         EMU_LAUNCH(debig_png_defilter_kernel<4>, n, 256, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images, results, n);
