@@ -215,15 +215,10 @@ static int launch_inflate(uint32_t width, uint32_t cls, hipStream_t s, const voi
                           const debig_stream *d_streams, debig_result *d_results, uint32_t n, const FixedTabs *tabs);
 static uint32_t chunk_bytes_override()
 {
-    // DEBIG_CHUNK_BYTES: compressed bytes per chunk task (default: by batch size, 32..256 KiB)
-    static int env_read = 0;
-    static uint32_t env_val = 0;
-    if (!env_read) {
-        const char *e = getenv("DEBIG_CHUNK_BYTES");
-        if (e && *e) env_val = (uint32_t)strtoul(e, nullptr, 0);
-        env_read = 1;
-    }
-    return env_val;
+    // DEBIG_CHUNK_BYTES: compressed bytes per chunk task (default: by batch size, 32..256 KiB).  Read
+    // at every call: tests cut small streams into many tasks with it.
+    const char *e = getenv("DEBIG_CHUNK_BYTES");
+    return e && *e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
 }
 static int launch_chunked(hipStream_t s, const void *d_in, void *d_out, const debig_stream *d_streams,
                           debig_result *d_results, uint32_t n, const FixedTabs *tabs, void *ws_, uint64_t ws_bytes)

@@ -316,6 +316,45 @@ def test_chunked_path_against_the_workgroup_path(gpu_device):
         assert a == c, (i, a, c)
 
 
+def test_chunked_path_many_small_tasks_agree_with_oracle(oracle, gpu_device, monkeypatch):
+    """DEBIG_CHUNK_BYTES = 1024 / 3072 cuts ordinary test streams into dozens of chunk tasks each, so the
+    block finder, the repair and chain kernels, the two-plane replay, the window walk and the translate
+    kernel run on thousands of task boundaries on the real hardware (kernel-to-kernel visibility
+    across XCDs is something the CPU emulator cannot show).  400 streams of mixed structure, a third
+    damaged; every answer must be the oracle's."""
+    import random
+
+    rng = random.Random(4242)
+    raws, caps = [], []
+    for it in range(400):
+        parts = []
+        for _ in range(rng.randint(1, 4)):
+            n = rng.randint(500, 40000)
+            parts.append(_payload(rng, n, rng.randrange(5)))
+        strat = rng.choice([zlib.Z_DEFAULT_STRATEGY] * 4 + [zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED])
+        c = zlib.compressobj(rng.choice([1, 4, 6, 9]), zlib.DEFLATED, -15, rng.choice([8, 9]), strat)
+        raw = b""
+        for p in parts:
+            raw += c.compress(p)
+            if rng.random() < 0.3:
+                raw += c.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH]))
+        raw += c.flush()
+        plain_len = sum(len(p) for p in parts)
+        r = rng.random()
+        if r < 0.2 and len(raw) > 100:
+            bad = bytearray(raw)
+            bad[rng.randrange(len(bad))] ^= 1 << rng.randrange(8)
+            raw = bytes(bad)
+        elif r < 0.33 and len(raw) > 100:
+            raw = raw[:rng.randint(50, len(raw) - 1)]
+        raws.append(raw)
+        caps.append(max(plain_len + rng.choice([0, 1, 64]), len(raw)))
+    for chunk in ("1024", "3072"):
+        monkeypatch.setenv("DEBIG_CHUNK_BYTES", chunk)
+        _check(oracle, gpu_device, raws, caps, widths=(0x20,), in_skew=int(chunk) % 7, out_skew=3)
+    monkeypatch.delenv("DEBIG_CHUNK_BYTES", raising=False)
+
+
 def test_invalid_width_is_rejected(gpu_device):
     pairs = workload.make_streams("fixed", 1, 4096)
     b = DeviceBatch.from_streams([pairs[0][0]], [8192], device=gpu_device)
