@@ -207,7 +207,7 @@ static int launch_split(hipStream_t s, const void *d_in, void *d_out, const debi
     return 0;
 }
 
-// ---- the chunk-parallel path for large streams (inflate_chunk_kernel.inc): eleven small launches,
+// ---- the chunk-parallel path for large streams (inflate_chunk_kernel.inc): fourteen small launches,
 // no host synchronisation; sizes live in device memory, so every grid is laid out for the number of
 // chunk tasks the workspace could hold and surplus workgroups leave at once.  Returns 0, a
 // hipError_t, or -1 when the workspace is too small to try.
