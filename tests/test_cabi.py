@@ -194,3 +194,26 @@ def test_compat_archive_has_the_literal_inflate_symbol(native_lib):
     assert os.path.exists(ar), "python -m debigulator_amd.build makes it"
     out = os.popen(f"nm {ar}").read()
     assert " T inflate" in out and " U debig_inflate" in out
+
+
+def test_dispatch_plan_rules():
+    """debigulator_amd.batch.plan_batch mirrors csrc/host/debig_ctx.h (debig_pick_waves /
+    debig_plan_batch): few streams that are large on average, or thousands with a very large one
+    among them, go through chunk tasks; a skewed batch of 513..1024 is launched longest first."""
+    import numpy as np
+
+    from debigulator_amd import _native as N
+    from debigulator_amd.batch import STREAM_DTYPE, plan_batch
+
+    def streams(lens):
+        s = np.zeros(len(lens), dtype=STREAM_DTYPE)
+        s["in_len"] = lens
+        return s
+
+    assert plan_batch(streams([2 << 20] * 64)) == (None, N.WAVES_CHUNKED)
+    assert plan_batch(streams([400 << 10] * 256)) == (None, 0)                  # 0.4 MiB on average: workgroups
+    assert plan_batch(streams([20000] * 2000 + [8 << 20])) == (None, N.WAVES_CHUNKED)
+    assert plan_batch(streams([20000] * 2000 + [1 << 20])) == (None, 0)
+    assert plan_batch(streams([65536] * 8192)) == (None, 0)
+    order, waves = plan_batch(streams([1000] * 600 + [500000] * 200))
+    assert waves == 4 and list(order[:3]) == [600, 601, 602]
