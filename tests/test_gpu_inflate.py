@@ -355,6 +355,39 @@ def test_chunked_path_many_small_tasks_agree_with_oracle(oracle, gpu_device, mon
     monkeypatch.delenv("DEBIG_CHUNK_BYTES", raising=False)
 
 
+def test_batch_call_with_caller_workspace_is_graph_capturable(gpu_device):
+    """include/debig_hip.h: debig_hip_inflate_batch_ws allocates nothing and never synchronises, so the
+    launches of a step can be captured into a hipGraph and replayed (both the scan / LZ77 pair and
+    the chunk-parallel path; the workspace is the caller's)."""
+    import torch
+
+    from debigulator_amd import _native as N
+
+    for width, pairs in ((0x10, workload.make_streams("dynamic", 1500, 20000)),
+                         (0x20, workload.make_streams("dynamic", 6, 3 << 20))):
+        raws = [p[0] for p in pairs]
+        b = DeviceBatch.from_streams(raws, [len(p[1]) for p in pairs], device=gpu_device)
+        b.launch(waves_per_stream=width)  # allocates the batch's workspace, outside the capture
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream(device=gpu_device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            b.launch(waves_per_stream=width)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            b.launch(waves_per_stream=width)
+        for _ in range(2):
+            b.d_out.zero_()
+            b.d_results.zero_()
+            g.replay()
+            res = b.results()
+            assert (res["good"] == 1).all(), width
+            for i in (0, len(pairs) // 2, len(pairs) - 1):
+                assert b.output(i, res) == pairs[i][1].tobytes(), (width, i)
+
+
 def test_invalid_width_is_rejected(gpu_device):
     pairs = workload.make_streams("fixed", 1, 4096)
     b = DeviceBatch.from_streams([pairs[0][0]], [8192], device=gpu_device)
