@@ -3,6 +3,8 @@
 compared with zlib's (valid streams, recipients of the exact size).  The payloads carry what the
 block finder can stumble over: compressed data embedded as literals (real dynamic block headers at
 byte-aligned and, after a stored-block header, arbitrary positions), long runs, incompressible noise.
+Every stream is then damaged (flipped bits, cut short) and the chunk path compared with a whole
+workgroup per stream: status, size, CRC of the decoded prefix.
     python tools/fuzz_chunked_gpu.py [SECONDS=240] [SEED=1]"""
 import os, random, sys, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -73,6 +75,35 @@ while time.time() - t0 < budget:
             assert res[i]["good"] == 1 and int(res[i]["final_size"]) == len(plain), (seed, chunk, i, res[i])
             assert b.output(i, res) == plain, (seed, chunk, i)
         del b
+    # damaged copies (a flipped bit, a cut): the chunk path must return what a whole workgroup per
+    # stream returns -- status, size and every decoded byte
+    os.environ.pop("DEBIG_CHUNK_BYTES", None)
+    bad, bcaps = [], []
+    for raw, plain in pairs:
+        b2 = bytearray(raw)
+        if rng.random() < 0.7:
+            for _ in range(rng.randint(1, 2)):
+                b2[rng.randrange(len(b2))] ^= 1 << rng.randrange(8)
+        else:
+            b2 = b2[:rng.randint(len(b2) // 4, len(b2) - 1)]
+        bad.append(bytes(b2))
+        bcaps.append(max(len(plain) + 4096, len(b2)))
+    got = {}
+    for width in (8, N.WAVES_CHUNKED):
+        b = DeviceBatch.from_streams(bad, bcaps, out_skew=3)
+        b.launch(waves_per_stream=width)
+        res = b.results()
+        host = b.outputs_host()
+        rows = []
+        for i in range(len(bad)):
+            off = int(b.streams_host[i]["out_off"])
+            n = int(res[i]["final_size"]) if res[i]["final_set"] else 0
+            rows.append((int(res[i]["good"]), int(res[i]["status"]), int(res[i]["final_set"]), n,
+                         zlib.crc32(host[off:off + n].tobytes())))
+        got[width] = rows
+        del b
+    for i, (a, c) in enumerate(zip(got[8], got[N.WAVES_CHUNKED])):
+        assert a == c, (seed, "damaged", i, a, c)
     rounds += 1
     streams += 3 * len(pairs)
     nbytes += 3 * sum(caps)
