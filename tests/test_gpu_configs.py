@@ -122,3 +122,42 @@ def test_drop_in_decode_gz_batch(gpu_device):
     gz = workload.gzip_member(workload.encode("dynamic", plain), plain)
     good, out = api.decode_gz(gz)
     assert good == 1 and out == plain.tobytes()
+
+
+def test_decode_png_in_chunk_tasks_with_the_aliasing_replay(gpu_device, oracle, monkeypatch):
+    """decode_png's inflate forced through chunk tasks of 1 and 2 KiB (DEBIG_WAVES_PER_STREAM = 0x20,
+    DEBIG_CHUNK_BYTES): RGBA and palette images of odd sizes, every filter type, several noise
+    levels -- the reference's buffer-aliasing replay (P2: the last 772 bytes of the scanline stream)
+    then falls into the last task's planes, on a task boundary, or hands the stream back.  Every
+    image must equal the oracle's decode_png, and the reference's sample files their digests."""
+    import random
+
+    from debigulator_amd.png_device import DevicePngBatch
+
+    rng = random.Random(99)
+    pngs = []
+    for it in range(48):
+        ct = rng.choice([6, 6, 6, 3])
+        w, h = rng.randint(20, 420), rng.randint(20, 300)
+        p, _ = workload.make_png(8100 + it, w, h, ct=ct, ftype=rng.choice([0, 1, 2, 3, 4, 5]),
+                                 noise=rng.choice([1, 3, 8, 24, workload.CFG4_NOISE]), enc="dynamic",
+                                 idat_chunk=rng.choice([8192, 65536]))
+        pngs.append(p)
+    gold = json.load(open(os.path.join(GOLD, "resources.json")))["png"]
+    files = [f for f in sorted(glob.glob(os.path.join(GOLD, "resources", "*.png")))
+             if not f.endswith("backgrounddetailed1.png")]
+    monkeypatch.setenv("DEBIG_WAVES_PER_STREAM", "0x20")
+    for chunk in ("1024", "2048"):
+        monkeypatch.setenv("DEBIG_CHUNK_BYTES", chunk)
+        b = DevicePngBatch(pngs + [open(f, "rb").read() for f in files], device=gpu_device)
+        b.launch()
+        res, ires = b.results()
+        for i, p in enumerate(pngs):
+            good, want = oracle.decode_png(p)
+            assert int(ires[i]["good"] and res[i]["good"]) == good, (chunk, i)
+            if good:
+                assert np.array_equal(b.rgba(i), want), (chunk, i)
+        for k, f in enumerate(files):
+            assert sha(b.rgba(len(pngs) + k).tobytes()) == gold[os.path.basename(f)]["rgba_sha256"], (chunk, f)
+    monkeypatch.delenv("DEBIG_CHUNK_BYTES", raising=False)
+    monkeypatch.delenv("DEBIG_WAVES_PER_STREAM", raising=False)
