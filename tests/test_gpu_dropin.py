@@ -406,3 +406,36 @@ def test_large_streams_take_the_chunk_parallel_path_through_the_c_calls(api, mon
     outs = api.decode_png_batch([png, png, png])
     for good, rgba in outs:
         assert good == 1 and np.array_equal(np.asarray(rgba).reshape(1024, 4096), pix)
+
+
+def test_gunzip_batch_large_members_go_through_chunk_tasks(api):
+    """Files of a few LARGE gzip members (3-6 MB each, zlib level 6 and 9, a stored one): the
+    members are inflated in chunk tasks (few streams, > 1 MiB of input each), and the next member's
+    header is found from debig_result.in_end_bits of the chunk path -- the input span of every
+    stream runs on into the following members (DEBIG_STREAM_NO_REF_GATES), whose block headers the
+    block finder also sees.  python's gzip module is the referee."""
+    import gzip
+    import random
+
+    rng = random.Random(17)
+
+    def blob(n):
+        words = [bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(2, 9))) for _ in range(500)]
+        out = bytearray()
+        while len(out) < n:
+            out += rng.choice(words) + b" "
+        return bytes(out[:n])
+
+    files, want = [], []
+    for f in range(4):
+        parts = [blob(rng.randint(3 << 20, 6 << 20)) for _ in range(rng.randint(1, 3))]
+        raw = b""
+        for k, p in enumerate(parts):
+            raw += _gz_member(p, rng.choice([6, 9]) if (f + k) % 4 else 0, name=b"member" if k else None)
+        files.append(raw)
+        want.append((b"".join(parts), len(parts)))
+        assert gzip.decompress(raw) == want[-1][0]
+    got = api.gunzip_batch(files, [len(w[0]) + 8 for w in want])
+    for i, ((st, out, members), (plain, nmem)) in enumerate(zip(got, want)):
+        assert st == 0, (i, api.GZ_STATUS[st])
+        assert members == nmem and out == plain, i
