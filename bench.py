@@ -26,6 +26,15 @@ include/debig_hip.h) over this rank's whole shard, inputs already resident in HB
   cpu_baseline  the compiled reference (oracle/_ref; or the oracle port if that prebuilt library
                 is absent) on the host cores: one thread per kind, blended, and all cores.
 
+Default run (`--config cfg2`, no --no-cfg5): the line also carries `cfg5_strong`, BASELINE config 5
+measured by the same command on the same ranks -- 65536 gzip members of 1 MiB, member i -> GPU
+i mod N, strong scaling (value, ms_per_step, roofline on C + D, max-over-ranks time) -- so the
+SCALE runs (`--gpus 1/2/4/8`, no other flag) report both the weak-scaling headline and config 5.
+`value` of the line itself stays the cfg2 headline at every N.
+
+`--dist`: initialise torch.distributed even at N = 1 (backend nccl = RCCL at world size 1: loads
+librccl, runs init_process_group and the shard-map broadcast on a cuda tensor).
+
 Multi-GPU: `--gpus N` with N > 1 started WITHOUT a torch.distributed environment spawns
 `python -m torch.distributed.run --nproc-per-node N` on itself (before anything touches the
 GPU) and passes rank 0's JSON line through; started by torch.distributed.run it is a rank.
@@ -66,6 +75,9 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the N>1 code path on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--dist", action="store_true", help="initialise torch.distributed even at N = 1")
+    ap.add_argument("--no-cfg5", action="store_true", help="cfg2: skip the cfg5_strong record")
+    ap.add_argument("--cfg5-steps", type=int, default=3, help="timed steps of the cfg5_strong record")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 100 if args.config == "cfg2" else 5
@@ -146,7 +158,7 @@ def _cpu_worker(job):
     return nbytes, time.perf_counter() - t0
 
 
-def cpu_baseline(samples, label):
+def cpu_baseline(samples, label, do_all_cores=True):
     """samples: {kind: [(raw, recipient_size, decompressed size)]}.  Reference (or port) on the host
     cores: one thread per kind, one thread blended, and every usable core (one process each)."""
     import multiprocessing as mp
@@ -164,6 +176,8 @@ def cpu_baseline(samples, label):
     cores = max(1, min(host["usable_cores"], 16))
     all_core = None
     try:
+        if not do_all_cores:
+            raise RuntimeError("not run (this process may hold a GPU context)")
         ctx = mp.get_context("spawn")  # never fork a process that holds a GPU context
         with ctx.Pool(cores) as pool:
             t0 = time.perf_counter()
@@ -185,15 +199,34 @@ def cpu_baseline(samples, label):
     }
 
 
-def run_cpu_baseline(args, world, samples, label):
-    """rank 0 at N=1 only, and BEFORE this process initialises the GPU: the all-core leg starts
-    worker processes, which a process holding a GPU context must not do on this pool."""
-    if args.no_cpu_baseline or world != 1:
+def run_cpu_baseline(args, rank, samples, label, all_cores=True):
+    """rank 0 only, and BEFORE this process initialises the GPU or torch.distributed (cfg2 / cfg5: the
+    samples are global units 0.., the same at every N): the all-core leg starts worker processes,
+    which a process holding a GPU context must not do on this pool.  all_cores = False: no child
+    processes (cfg4 at N > 1, where the sample is this rank's first image)."""
+    if args.no_cpu_baseline or rank != 0:
         return None
     try:
-        return cpu_baseline(samples, label)
+        return cpu_baseline(samples, label, all_cores)
     except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
         return {"value": None, "unit": "GB/s decompressed", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+
+
+def early_samples(args):
+    """cfg2 / cfg5 baseline samples, built without the shard map: global units 0.. of the workload"""
+    from debigulator_amd import workload
+
+    if args.config == "cfg5":
+        n = 8
+        pairs = [workload.make_stream("dynamic", g % CFG5_DISTINCT, CFG5_MEMBER_BYTES) for g in range(n)]
+        raws = [workload.gzip_member(r, p)[10:-8] for r, p in pairs]
+        return ({"gzip_dynamic": [(r, max(CFG5_MEMBER_BYTES + 1, len(r)), CFG5_MEMBER_BYTES) for r in raws]},
+                f"gzip members 0..{n - 1} of the timed job (1 MiB each, dynamic Huffman)")
+    out = {}
+    for kind in ("fixed", "stored"):
+        ps = [workload.make_stream(kind, g, STREAM_BYTES) for g in range(128)]
+        out[kind] = [(p[0], max(STREAM_BYTES + 1, len(p[0])), STREAM_BYTES) for p in ps]
+    return out, "fixed-Huffman and stored streams 0..127 (64 KiB each) of the timed workload"
 
 
 # ---------------------------------------------------------------- GPU side
@@ -233,23 +266,137 @@ def kernel_sources_digest():
     return h.hexdigest()
 
 
+def build_cfg5(args, torch, np, mine, world, dev, ncpu):
+    """BASELINE config 5 on this rank: member i -> GPU i mod N.  Distinct payloads: seed = i mod 512;
+    this rank's members cycle through its 512/N seeds, replicated ON THE DEVICE into one arena per
+    direction (every member has its own input and output bytes in HBM).  Returns the batch, its
+    verify() and the byte counts."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from debigulator_amd import _native, workload
+    from debigulator_amd.batch import RESULT_DTYPE, DeviceBatch, pack_streams
+
+    assert args.members % world == 0
+    n_mine = len(mine)
+    uniq = max(1, min(n_mine, CFG5_DISTINCT // world))
+    with ThreadPoolExecutor(ncpu) as ex:
+        pairs = list(ex.map(lambda g: workload.make_stream("dynamic", int(g) % CFG5_DISTINCT, CFG5_MEMBER_BYTES),
+                            mine[:uniq]))
+    members = [workload.gzip_member(r, p) for r, p in pairs]
+    raws_u = [m[10:-8] for m in members]  # decode_gz's host side: 10-byte header, 8-byte trailer
+    caps_u = [max(CFG5_MEMBER_BYTES + 1, len(r)) for r in raws_u]
+    in_block, st_block, out_block = pack_streams(raws_u, caps_u)
+    reps = (n_mine + uniq - 1) // uniq
+    streams = np.tile(st_block, reps)[:n_mine].copy()
+    k = np.arange(n_mine) // uniq
+    streams["in_off"] += (k * len(in_block)).astype(np.uint64)
+    streams["out_off"] += (k * out_block).astype(np.uint64)
+    batch = DeviceBatch.__new__(DeviceBatch)
+    batch.torch, batch.device, batch.n, batch.streams_host = torch, torch.device(dev), n_mine, streams
+    blk = torch.from_numpy(in_block).to(dev)
+    batch.d_in = blk.repeat(reps)
+    batch.d_out = torch.zeros(out_block * reps, dtype=torch.uint8, device=dev)
+    batch.order, batch.planned_waves, batch.d_ws = None, 0, None
+    batch.d_streams = torch.from_numpy(streams.view(np.uint8).reshape(-1)).to(dev)
+    batch.d_results = torch.zeros(n_mine * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    batch.lib = _native.lib()
+
+    def verify():
+        import struct
+
+        from debigulator_amd.checksum import CRC32, DeviceChecksums
+
+        res = batch.results()
+        assert (res["good"] == 1).all(), "a member failed"
+        assert (res["final_size"] == CFG5_MEMBER_BYTES).all(), "wrong size"
+        spans = [(int(streams[i]["out_off"]), CFG5_MEMBER_BYTES) for i in range(n_mine)]
+        ck = DeviceChecksums(batch.d_out, spans, CRC32)
+        ck.launch()
+        want = np.array([struct.unpack("<I", members[i % uniq][-8:-4])[0] for i in range(n_mine)], dtype=np.uint32)
+        assert (np.asarray(ck.results(), dtype=np.uint32) == want).all(), "a member's CRC-32 differs"
+        for i in sorted({0, n_mine // 2, n_mine - 1}):
+            assert batch.output(i, res) == pairs[i % uniq][1].tobytes(), f"member {i} differs"
+        return res
+
+    name = (f"cfg5: {args.members} gzip members of 1 MiB (text-like, dynamic Huffman), member i -> GPU "
+            f"i mod {world}; seed 0xDEB16 + (i mod {CFG5_DISTINCT}), each member has its own bytes in HBM")
+    return batch, verify, int(streams["in_len"].sum()), CFG5_MEMBER_BYTES * n_mine, name
+
+
+def timed_steps(torch, np, dist, coll_dev, batch, verify, steps, warmup, c_bytes, d_bytes):
+    """W untimed launches, the bit-exactness gate, then exactly K launches between barrier + sync on
+    both sides.  Returns (max-over-ranks seconds, this rank's mean step in ms from events on the
+    launch stream, job D bytes, job C bytes, results)."""
+    for _ in range(warmup):
+        batch.launch()
+    torch.cuda.synchronize()
+    res = verify()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for k in range(steps):
+        batch.launch()
+        ev[k + 1].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+    tot = torch.tensor([float(d_bytes), float(c_bytes)], dtype=torch.float64, device=coll_dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    step_ms = float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(steps)]))
+    return float(t.item()), step_ms, float(tot[0].item()), float(tot[1].item()), res
+
+
+def roof(c, d, ms, what, launches):
+    ach = (c + d) / (ms * 1e-3) / 1e9
+    return {"kernel": what, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_step": c + d,
+            "avg_step_ms": ms, "decompressed_GBps": d / ms / 1e6, "launches_per_step": launches}
+
+
+SPLIT_WHAT = ("one step = debig_split_plan_kernel + debig_scan_kernel + debig_lz_kernel (+ debig_inflate_kernel for "
+              "streams handed back: none here), whole batch on rank 0")
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
 
-    import numpy as np
-    import torch
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    cfg5 = args.config == "cfg5"
+    cfg4 = args.config == "cfg4"
+
+    # ---- CPU baseline first (rank 0, any N): nothing has touched the GPU or torch.distributed yet
+    cpu_line = None
+    if not cfg4 and rank == 0 and not args.no_cpu_baseline:
+        samples, sample_label = early_samples(args)
+        cpu_line = run_cpu_baseline(args, rank, samples, sample_label)
+
+    import numpy as np
+    import torch
+
     dist = None
-    if world > 1:
+    if world > 1 or args.dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # --dist at N = 1, started without a launcher
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1]))
+            s.close()
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.one_device:
             local_rank = 0
         if args.backend == "nccl":
@@ -258,7 +405,7 @@ def main():
             dist.init_process_group(args.backend)
     dev = f"cuda:{local_rank}"
     coll_dev = dev if args.backend == "nccl" else "cpu"  # where collective tensors live
-    if world > 1:
+    if dist is not None:
         torch.cuda.set_device(local_rank)
 
     from concurrent.futures import ThreadPoolExecutor
@@ -267,16 +414,15 @@ def main():
     from debigulator_amd.batch import DeviceBatch
 
     ncpu = max(1, min(16, (os.cpu_count() or 8) // max(1, min(world, 8))))
-    cfg5 = args.config == "cfg5"
-    cfg4 = args.config == "cfg4"
 
     # ---- shard map: rank 0 builds it, RCCL broadcasts it (the only collective on the path)
-    n_units = args.members if cfg5 else world * (args.images if cfg4 else args.streams)
-    if world > 1:
-        smap = shard.broadcast_shard_map(n_units, coll_dev, dist)
-        mine = shard.my_streams(smap, rank)  # global ids of this rank's units, in local order
-    else:
-        mine = np.arange(n_units, dtype=np.int64)  # one rank owns everything; no GPU call yet (see below)
+    def my_units(n_units):
+        if dist is not None:
+            smap = shard.broadcast_shard_map(n_units, coll_dev, dist)
+            return shard.my_streams(smap, rank)  # global ids of this rank's units, in local order
+        return np.arange(n_units, dtype=np.int64)  # one rank owns everything
+
+    mine = my_units(args.members if cfg5 else world * (args.images if cfg4 else args.streams))
 
     kinds = {}
     if cfg4:
@@ -294,7 +440,7 @@ def main():
         samples = {"png_idat_stream": [(it0["raw"], est0, est0 - 1)]}
         sample_label = (f"inflate() of ONE image's IDAT stream ({len(it0['raw']) / 1e6:.0f} MB -> {(est0 - 1) / 1e6:.0f} MB of "
                         f"filtered rows); the reference's de-filter loops are not in this number")
-        cpu_line = run_cpu_baseline(args, world, samples, sample_label)
+        cpu_line = run_cpu_baseline(args, rank, samples, sample_label, all_cores=dist is None)
         torch.cuda.set_device(local_rank)
         pbatch = DevicePngBatch(pngs, device=dev)
         batch = pbatch  # .launch() = inflate + de-filter
@@ -324,10 +470,6 @@ def main():
         all_pairs = pairs_keep["fixed"] + pairs_keep["stored"]
         raws = [p[0] for p in all_pairs]
         caps = [max(STREAM_BYTES + 1, len(r)) for r in raws]
-        samples = {k: [(p[0], max(STREAM_BYTES + 1, len(p[0])), STREAM_BYTES) for p in pairs_keep[k][:128]]
-                   for k in ("fixed", "stored")}
-        sample_label = "128 fixed-Huffman + 128 stored streams of 64 KiB from the timed batch"
-        cpu_line = run_cpu_baseline(args, world, samples, sample_label)
         torch.cuda.set_device(local_rank)
         batch = DeviceBatch.from_streams(raws, caps, device=dev)
         c_kind = {k: sum(len(p[0]) for p in v) for k, v in pairs_keep.items()}
@@ -352,104 +494,18 @@ def main():
                          f"batch per step (one 64 KiB block per stream; stored = 65535+1 byte blocks), "
                          f"seed 0xDEB16+i")
     else:
-        # ---- cfg5: member i -> GPU i mod N.  Distinct payloads: seed = i mod 512; this rank's
-        # members cycle through its 512/N seeds, replicated ON THE DEVICE into one arena per
-        # direction (every member has its own input and output bytes in HBM)
-        assert args.members % world == 0
-        n_mine = len(mine)
-        uniq = max(1, min(n_mine, CFG5_DISTINCT // world))
-        with ThreadPoolExecutor(ncpu) as ex:
-            pairs = list(ex.map(lambda g: workload.make_stream("dynamic", int(g) % CFG5_DISTINCT, CFG5_MEMBER_BYTES),
-                                mine[:uniq]))
-        members = [workload.gzip_member(r, p) for r, p in pairs]
-        raws_u = [m[10:-8] for m in members]  # decode_gz's host side: 10-byte header, 8-byte trailer
-        caps_u = [max(CFG5_MEMBER_BYTES + 1, len(r)) for r in raws_u]
-        from debigulator_amd.batch import pack_streams
-
-        samples = {"gzip_dynamic": [(raws_u[i], caps_u[i], CFG5_MEMBER_BYTES) for i in range(min(8, uniq))]}
-        sample_label = f"{min(8, uniq)} of the timed gzip members (1 MiB each, dynamic Huffman)"
-        cpu_line = run_cpu_baseline(args, world, samples, sample_label)
         torch.cuda.set_device(local_rank)
-        in_block, st_block, out_block = pack_streams(raws_u, caps_u)
-        reps = (n_mine + uniq - 1) // uniq
-        streams = np.tile(st_block, reps)[:n_mine].copy()
-        k = np.arange(n_mine) // uniq
-        streams["in_off"] += (k * len(in_block)).astype(np.uint64)
-        streams["out_off"] += (k * out_block).astype(np.uint64)
-        batch = DeviceBatch.__new__(DeviceBatch)
-        batch.torch, batch.device, batch.n, batch.streams_host = torch, torch.device(dev), n_mine, streams
-        blk = torch.from_numpy(in_block).to(dev)
-        batch.d_in = blk.repeat(reps)
-        batch.d_out = torch.zeros(out_block * reps, dtype=torch.uint8, device=dev)
-        batch.order, batch.planned_waves, batch.d_ws = None, 0, None
-        batch.d_streams = torch.from_numpy(streams.view(np.uint8).reshape(-1)).to(dev)
-        from debigulator_amd.batch import RESULT_DTYPE
-        from debigulator_amd import _native
-
-        batch.d_results = torch.zeros(n_mine * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-        batch.lib = _native.lib()
-        c_bytes = int(streams["in_len"].sum())
-        d_bytes = CFG5_MEMBER_BYTES * n_mine
+        batch, verify, c_bytes, d_bytes, workload_name = build_cfg5(args, torch, np, mine, world, dev, ncpu)
         unit_bytes = CFG5_MEMBER_BYTES
 
-        def verify():
-            import struct
-
-            from debigulator_amd.checksum import CRC32, DeviceChecksums
-
-            res = batch.results()
-            assert (res["good"] == 1).all(), "a member failed"
-            assert (res["final_size"] == CFG5_MEMBER_BYTES).all(), "wrong size"
-            spans = [(int(streams[i]["out_off"]), CFG5_MEMBER_BYTES) for i in range(n_mine)]
-            ck = DeviceChecksums(batch.d_out, spans, CRC32)
-            ck.launch()
-            want = np.array([struct.unpack("<I", members[i % uniq][-8:-4])[0] for i in range(n_mine)], dtype=np.uint32)
-            assert (np.asarray(ck.results(), dtype=np.uint32) == want).all(), "a member's CRC-32 differs"
-            for i in sorted({0, n_mine // 2, n_mine - 1}):
-                assert batch.output(i, res) == pairs[i % uniq][1].tobytes(), f"member {i} differs"
-            return res
-
-        workload_name = (f"cfg5: {args.members} gzip members of 1 MiB (text-like, dynamic Huffman), member i -> GPU "
-                         f"i mod {world}; seed 0xDEB16 + (i mod {CFG5_DISTINCT}), each member has its own bytes in HBM")
-
-    for _ in range(args.warmup):
-        batch.launch()
-    torch.cuda.synchronize()
-    res = verify()  # ---- bit-exactness gate (untimed)
-
     # ---- timed region: exactly K steps between barrier+sync on both sides
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev[0].record()
-    for k in range(args.steps):
-        batch.launch()
-        ev[k + 1].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-    tot = torch.tensor([float(d_bytes), float(c_bytes)], dtype=torch.float64, device=coll_dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt_max = float(t.item())
-    step_ms = float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]))
+    dt_max, step_ms, job_d, job_c, res = timed_steps(torch, np, dist, coll_dev, batch, verify, args.steps, args.warmup,
+                                                     c_bytes, d_bytes)
 
+    line = None
     if rank == 0:
-        job_d, job_c = float(tot[0].item()), float(tot[1].item())
         value = job_d * args.steps / dt_max / 1e9
         digest = kernel_sources_digest()
-
-        def roof(c, d, ms, what, launches):
-            ach = (c + d) / (ms * 1e-3) / 1e9
-            return {"kernel": what, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_step": c + d,
-                    "avg_step_ms": ms, "decompressed_GBps": d / ms / 1e6, "launches_per_step": launches}
-
         split = len(res) > 1024  # include/debig_hip.h: what the library picks from the batch size
         if cfg4:
             # inflate reads C and writes the filtered rows S; the de-filter reads S and writes the pixels P
@@ -458,12 +514,9 @@ def main():
                     "launches per stream group) + debig_png_defilter_kernel; algorithmic bytes C + 2 S + P")
             rl = roof(c_bytes + 2 * s_bytes, d_bytes, step_ms, what, None)
             rl["decompressed_GBps"] = d_bytes / step_ms / 1e6
-        what = ("one step = debig_split_plan_kernel + debig_scan_kernel + debig_lz_kernel (+ debig_inflate_kernel for "
-                "streams handed back: none here), whole batch on rank 0" if split else
-                "one step = one debig_inflate(_mw)_kernel launch, whole batch on rank 0")
-        lps = 4 if split else 1
-        if not cfg4:
-            rl = roof(c_bytes, d_bytes, step_ms, what, lps)
+        else:
+            rl = roof(c_bytes, d_bytes, step_ms, SPLIT_WHAT if split else
+                      "one step = one debig_inflate(_mw)_kernel launch, whole batch on rank 0", 4 if split else 1)
         if not cfg5 and not cfg4:
             tr, src = pmc_traffic(digest, args.streams / STREAMS_PER_KIND)
             rl["traffic"] = tr
@@ -498,7 +551,7 @@ def main():
             },
             "roofline": rl,
         }
-        if world > 1:
+        if dist is not None:
             line["config"]["sharding"] = (f"round-robin by unit id over {world} ranks, shard map broadcast "
                                           f"({args.backend}), no payload collective")
         nw = res["n_windows"].astype(np.float64).sum()
@@ -516,8 +569,38 @@ def main():
                               4 if len(r) > 1024 else 1)
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
+
+    # ---- BASELINE config 5 beside the cfg2 headline (every rank takes part: it has its own barriers)
+    if not cfg4 and not cfg5 and not args.no_cfg5:
+        del batch
+        kinds.clear()
+        torch.cuda.empty_cache()
+        mine5 = my_units(args.members)
+        b5, verify5, c5, d5, name5 = build_cfg5(args, torch, np, mine5, world, dev, ncpu)
+        dt5, ms5, jd5, jc5, res5 = timed_steps(torch, np, dist, coll_dev, b5, verify5, args.cfg5_steps, 1, c5, d5)
+        if rank == 0:
+            r5 = roof(c5, d5, ms5, SPLIT_WHAT + " (rank 0's shard; member payloads, CRC-32 checked outside the timed region)",
+                      4 if len(res5) > 1024 else 1)
+            line["cfg5_strong"] = {
+                "value": jd5 * args.cfg5_steps / dt5 / 1e9,
+                "unit": "GB/s",
+                "scaling": "strong",
+                "n_gpus": world,
+                "steps": args.cfg5_steps,
+                "warmup": 1,
+                "ms_per_step": dt5 / args.cfg5_steps * 1e3,
+                "members_job": args.members,
+                "members_per_gpu": len(res5),
+                "decompressed_bytes_job": jd5,
+                "compressed_bytes_job": jc5,
+                "workload": name5,
+                "bit_exact_checked": "every member's size/good flag + CRC-32 (on the GPU), 3 members byte for byte",
+                "roofline": r5,
+            }
+        del b5
+    if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

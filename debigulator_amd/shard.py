@@ -23,7 +23,7 @@ def broadcast_shard_map(n_streams, device, dist=None):
     smap = torch.zeros((n_streams, 3), dtype=torch.int64, device=device)
     if rank == 0:
         smap.copy_(torch.from_numpy(build_shard_map(world, n_streams)))
-    if dist is not None and world > 1:
+    if dist is not None:  # world size 1 included: the collective runs whenever a process group exists
         dist.broadcast(smap, src=0)
     return smap
 
