@@ -79,6 +79,25 @@ def test_cfg4_roundtrip_property_large(gpu_device):
     assert np.array_equal(b.rgba(1).reshape(2048, 8192), x)
 
 
+def test_cfg4_one_full_size_image(gpu_device):
+    """BASELINE config 4 at its real size: ONE 8192 x 8192 RGBA image, every row Paeth, ratio about 3:1
+    (a 268 MB scanline stream: several hundred chunk tasks, offsets beyond 2^28 inside one recipient,
+    8192-pixel rows in the de-filter).  Property (the oracle needs minutes here): the decoded pixels
+    are the generator's, through the path the library picks for the batch (chunk tasks)."""
+    from debigulator_amd.png_device import DevicePngBatch
+
+    side = 8192
+    png, pix = workload.make_png(9001, side, side, ct=6, ftype=4, noise=workload.CFG4_NOISE, enc="dynamic",
+                                 idat_chunk=65536)
+    assert 2.8 < side * (side * 4 + 1) / len(png) < 3.2
+    b = DevicePngBatch([png], device=gpu_device)
+    b.launch()
+    res, ires = b.results()
+    assert (res["good"] == 1).all() and (ires["good"] == 1).all()
+    assert int(res[0]["final_size"]) == side * (side * 4 + 1)
+    assert np.array_equal(b.rgba(0).reshape(side, side * 4), np.asarray(pix).reshape(side, side * 4))
+
+
 def test_cfg5_shape_gzip_members(gpu_device, oracle):
     """gzip members of 1 MiB (text-like, dynamic Huffman, EOB >= 8 bits so the tail rule never
     truncates): header located on the host, payloads inflated in one launch."""

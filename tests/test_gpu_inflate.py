@@ -276,44 +276,89 @@ def test_p2_aliasing_replay_every_width(gpu_device):
             assert got[width][i] == got[1][i], (width, n)
 
 
-def test_chunked_path_against_the_workgroup_path(gpu_device):
+def test_chunked_path_against_the_oracle(oracle, gpu_device):
     """DEBIG_WAVES_CHUNKED on streams of many chunk tasks (8 MiB image rows and text, the library's
     own chunk size), intact and damaged (a flipped bit early, in the middle, near the end; a
-    truncated stream; a recipient one byte short): status, size and every byte must equal what
-    debig_inflate_mw_kernel<8> -- pinned to the oracle by the other tests -- returns."""
-    import random
-
+    truncated stream; a recipient one byte short): good, size and every byte must be the ORACLE's,
+    for the chunk-parallel path and for debig_inflate_mw_kernel<8> (the kernel it hands damaged
+    streams to)."""
     rng = random.Random(77)
     pairs = workload.make_streams("png", 3, 8 << 20) + workload.make_streams("dynamic", 3, 8 << 20)
     raws, caps = [], []
     for raw, plain in pairs:
         raw = bytes(raw)
-        raws.append(raw); caps.append(len(plain))
+        raws.append(raw); caps.append(len(plain) + 1)
         for pos in (rng.randrange(50, 2000), len(raw) // 2 + rng.randrange(1000), len(raw) - rng.randrange(100, 3000)):
             bad = bytearray(raw)
             bad[pos] ^= 1 << rng.randrange(8)
             raws.append(bytes(bad)); caps.append(len(plain) + 4096)
     raws.append(raws[0][:len(raws[0]) * 2 // 3]); caps.append(caps[0])
-    raws.append(raws[0]); caps.append(caps[0] - 1)
-    b = DeviceBatch.from_streams(raws, caps, device=gpu_device, out_skew=3)
-    got = {}
-    for width in (8, 0x20):
-        b.d_out.zero_()
+    raws.append(raws[0]); caps.append(caps[0] - 2)  # one byte short of the output
+    _check(oracle, gpu_device, raws, caps, widths=(8, 0x20), out_skew=3)
+    # the intact ones really decode (the comparison above is not between two failures)
+    for i in (0, 4):
+        g, f, o, _ = oracle.inflate(raws[i], caps[i], want_stats=True)
+        assert g == 1 and f == caps[i] - 1
+
+
+def test_offsets_beyond_4_gib(oracle, gpu_device):
+    """64-bit offset arithmetic in every kernel: the streams sit BEHIND the 4 GiB mark of both arenas
+    (in_off, out_off > 2^32; sparse arenas: only the far end is ever touched).  Small streams of
+    every block type, a damaged one and one large enough for several chunk tasks; every width must
+    give the oracle's answer."""
+    import torch
+
+    from debigulator_amd.batch import DeviceBatch as DB, pack_streams
+
+    rng = random.Random(4096)
+    raws, caps = [], []
+    for kind in ("stored", "fixed", "dynamic"):
+        raw, plain = workload.make_stream(kind, 7, 40000)
+        raws.append(bytes(raw)); caps.append(max(len(plain) + 1, len(raw)))
+    bad = bytearray(raws[2]); bad[len(bad) // 2] ^= 0x10
+    raws.append(bytes(bad)); caps.append(caps[2] + 4096)
+    raw, plain = workload.make_stream("dynamic", 9, 3 << 20)
+    raws.append(bytes(raw)); caps.append(len(plain) + 1)
+    data = _payload(rng, 30000, 1)
+    raws.append(_zlib_raw(data, 6, zlib.Z_DEFAULT_STRATEGY, 9, 2, rng)); caps.append(len(data) + 1)
+    exp = [oracle.inflate(r, c, want_stats=True) for r, c in zip(raws, caps)]
+    in_arena, streams, out_bytes = pack_streams(raws, caps, in_skew=5, out_skew=3)
+    base_in, base_out = (1 << 32) + 4096 + 16, (1 << 32) + (1 << 20) + 32
+    streams = streams.copy()
+    streams["in_off"] += np.uint64(base_in)
+    streams["out_off"] += np.uint64(base_out)
+    b = DB.__new__(DB)
+    b.torch, b.device, b.n, b.streams_host = torch, torch.device(gpu_device), len(raws), streams
+    b.d_in = torch.empty(base_in + len(in_arena), dtype=torch.uint8, device=gpu_device)
+    b.d_in[base_in:] = torch.from_numpy(in_arena).to(gpu_device)
+    b.d_out = torch.empty(base_out + out_bytes, dtype=torch.uint8, device=gpu_device)
+    b.order, b.planned_waves, b.d_ws, b.chunk_groups = None, 0, None, None
+    b.dev_streams_host = streams
+    b.d_streams = torch.from_numpy(streams.view(np.uint8).reshape(-1)).to(gpu_device)
+    from debigulator_amd.batch import RESULT_DTYPE
+    from debigulator_amd import _native
+
+    b.d_results = torch.zeros(b.n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=gpu_device)
+    b.lib = _native.lib()
+    for width in WIDTHS:
+        b.d_out[base_out:].zero_()
         b.d_results.zero_()
         b.launch(waves_per_stream=width)
         res = b.results()
-        host = b.outputs_host()
-        rows = []
-        for i in range(len(raws)):
-            off, cap = int(b.streams_host[i]["out_off"]), int(b.streams_host[i]["out_cap"])
+        host = b.d_out[base_out:].cpu().numpy()
+        for i, (g, f, o, st) in enumerate(exp):
+            off = int(streams[i]["out_off"]) - base_out
+            cap = int(streams[i]["out_cap"])
             assert not host[off + cap:off + cap + 32].any(), (width, i)
-            n = int(res[i]["final_size"]) if res[i]["final_set"] else 0
-            rows.append((int(res[i]["good"]), int(res[i]["status"]), int(res[i]["final_set"]), n,
-                         hashlib.sha256(host[off:off + n].tobytes()).hexdigest()))
-        got[width] = rows
-    assert got[8][0][0] == 1 and got[8][4][0] == 1  # the intact ones decode
-    for i, (a, c) in enumerate(zip(got[8], got[0x20])):
-        assert a == c, (i, a, c)
+            if st.ub_flags & UB_EXCLUDED:
+                continue
+            assert res[i]["good"] == g, (width, i, res[i])
+            if f is None:
+                assert res[i]["final_set"] == 0
+                continue
+            assert int(res[i]["final_size"]) == f, (width, i, res[i], f)
+            assert host[off:off + f].tobytes() == o, f"width {width:#x} stream {i}: bytes differ"
+    assert exp[0][0] == 1 and exp[4][0] == 1 and exp[3][0] in (0, 1)
 
 
 def test_chunked_path_many_small_tasks_agree_with_oracle(oracle, gpu_device, monkeypatch):
