@@ -13,19 +13,6 @@
 #include "png_kernel.inc"
 #include "checksum_kernel.inc"
 
-// one wavefront per workgroup; enough workgroups in flight to fill 256 CUs x (LDS-limited)
-// resident waves, the rest grid-strides
-static inline uint32_t pick_grid(uint32_t n, uint32_t per_cu)
-{
-    int dev = 0;
-    hipDeviceProp_t p;
-    uint32_t cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
-        cus = (uint32_t)p.multiProcessorCount;
-    uint32_t cap = cus * per_cu * 4u; /* several waves of workgroups: streams differ in length */
-    return n < cap ? n : cap;
-}
-
 // BTYPE 1 tables, built once per device by a tiny kernel and then only copied into LDS.  Two
 // images: the single-wavefront kernel and the multi-wavefront kernels use different direct
 // table widths (TabCfg<NW>).
@@ -128,13 +115,12 @@ int debig_hip_gather(const void *d_src_arena, void *d_dst_arena, const debig_cop
 static uint32_t auto_waves_per_stream(uint32_t n)
 {
     // DEBIG_WAVES_PER_STREAM=1|2|4|0x41|0x42 overrides the choice (measurements, bisecting)
-    static int env_read = 0;
+    static std::once_flag env_once; /* the drop-in API allows concurrent callers */
     static uint32_t env_val = 0;
-    if (!env_read) {
+    std::call_once(env_once, [] {
         const char *e = getenv("DEBIG_WAVES_PER_STREAM");
         if (e && *e) env_val = (uint32_t)strtoul(e, nullptr, 0);
-        env_read = 1;
-    }
+    });
     if (env_val) return env_val;
     if (n <= 256u) return 8u;
     if (n <= 512u) return 4u;
@@ -151,9 +137,33 @@ static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a
 struct DefaultWs {
     void *ptr;
     uint64_t bytes;
+    // ONE buffer per device shared by every caller that brings no workspace: a call's group of
+    // launches holds `use` while it is enqueued, waits for the event of the group before it and
+    // records the event behind itself -- two host threads or two HIP streams never interleave their
+    // plan / scan / lz launches on the buffer (their groups run one after the other on the device).
+    std::mutex use;
+    hipEvent_t done;
+    int has_done;
 };
 static DefaultWs g_default_ws[64];
-static const DefaultWs *default_workspace(hipStream_t s)
+struct SharedWsUse { /* RAII over one call's launches on the default workspace (nullptr: caller-owned workspace) */
+    DefaultWs *w;
+    hipStream_t s;
+    SharedWsUse(DefaultWs *w_, hipStream_t s_) : w(w_), s(s_)
+    {
+        if (!w) return;
+        w->use.lock();
+        if (w->has_done) (void)hipStreamWaitEvent(s, w->done, 0);
+    }
+    ~SharedWsUse()
+    {
+        if (!w) return;
+        if (!w->has_done && hipEventCreateWithFlags(&w->done, hipEventDisableTiming) == hipSuccess) w->has_done = 1;
+        if (w->has_done) (void)hipEventRecord(w->done, s);
+        w->use.unlock();
+    }
+};
+static DefaultWs *default_workspace(hipStream_t s)
 {
     const int dev = launch_device(s);
     if (dev < 0 || dev >= 64) return nullptr;
@@ -320,20 +330,31 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
     const FixedTabs *ft = fixed_tables(s);
     if (!ft) return (int)hipErrorOutOfMemory;
     if (waves_per_stream == DEBIG_WAVES_CHUNKED) {
+        DefaultWs *shared = nullptr;
         if (!d_workspace) {
-            const DefaultWs *w = default_workspace(s);
-            if (w) { d_workspace = w->ptr; workspace_bytes = w->bytes; }
+            shared = default_workspace(s);
+            if (shared) { d_workspace = shared->ptr; workspace_bytes = shared->bytes; }
         }
-        int rc = d_workspace ? launch_chunked(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes) : -1;
+        int rc = -1;
+        if (d_workspace) {
+            SharedWsUse hold(shared, s);
+            rc = launch_chunked(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes);
+        }
         if (rc >= 0) return rc;
+        d_workspace = nullptr;
         waves_per_stream = n <= 256u ? 8u : n <= 512u ? 4u : n <= 1024u ? 2u : 1u; /* no usable workspace */
     }
     if (waves_per_stream == DEBIG_WAVES_SPLIT) {
+        DefaultWs *shared = nullptr;
         if (!d_workspace) {
-            const DefaultWs *w = default_workspace(s);
-            if (w) { d_workspace = w->ptr; workspace_bytes = w->bytes; }
+            shared = default_workspace(s);
+            if (shared) { d_workspace = shared->ptr; workspace_bytes = shared->bytes; }
         }
-        int rc = d_workspace ? launch_split(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes) : -1;
+        int rc = -1;
+        if (d_workspace) {
+            SharedWsUse hold(shared, s);
+            rc = launch_split(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes);
+        }
         if (rc >= 0) return rc;
         waves_per_stream = 1; /* no usable workspace: the one-kernel path */
     }
@@ -355,6 +376,16 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
     return 0;
 }
 
+int debig_hip_init(void *hip_stream)
+{
+    // everything a first call would allocate or build lazily on the stream's device: the BTYPE 1
+    // table images (three allocations, three tiny kernels, one synchronisation).  After it a call
+    // with a caller-owned workspace enqueues kernels and nothing else: capturable into a hipGraph.
+    hipStream_t s = (hipStream_t)hip_stream;
+    DeviceGuard launch_guard(launch_device(s));
+    return fixed_tables(s) ? 0 : (int)hipErrorOutOfMemory;
+}
+
 int debig_hip_inflate_batch_ex(const void *d_in, void *d_out, const debig_stream *d_streams,
                                debig_result *d_results, uint32_t n, uint32_t waves_per_stream,
                                void *hip_stream)
@@ -373,13 +404,12 @@ int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d
 // overrides (measurements).
 static uint32_t defilter_waves(uint32_t n)
 {
-    static int env_read = 0;
+    static std::once_flag env_once;
     static uint32_t env_val = 0;
-    if (!env_read) {
+    std::call_once(env_once, [] {
         const char *e = getenv("DEBIG_DEFILTER_WAVES");
         if (e && *e) env_val = (uint32_t)strtoul(e, nullptr, 0);
-        env_read = 1;
-    }
+    });
     if (env_val == 1 || env_val == 2 || env_val == 4 || env_val == 8 || env_val == 16) return env_val;
     if (n <= 64u) return 16u; /* 32 images of 8192 x 8192: 52.5 -> 46.2 ms; from 128 images on 8 is as good */
     if (n <= 256u) return 8u;

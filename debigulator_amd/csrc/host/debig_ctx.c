@@ -45,6 +45,8 @@ void debig_ctx_release(uint32_t thread_id)
     buf_free(&c->crcs);
     buf_free(&c->copies);
     buf_free(&c->ws);
+    buf_free(&c->dense);
+    buf_free(&c->dense_list);
     if (c->pin_in.ptr) debig_hip_host_free(c->pin_in.ptr);
     if (c->pin_out.ptr) debig_hip_host_free(c->pin_out.ptr);
     c->pin_in.ptr = c->pin_out.ptr = NULL;
@@ -56,8 +58,17 @@ void debig_ctx_release(uint32_t thread_id)
 }
 
 /* ---- page-locked staging */
+/* The arenas are reused from call to call, but not hoarded: one that is more than 4 x what the call
+ * needs and larger than 256 MiB is given back first (10 thread ids x up to 16 device contexts each
+ * keep a pair of them). */
+#define DEBIG_PIN_KEEP (256ull << 20)
 static int pin_reserve(debig_devbuf *b, uint64_t bytes)
 {
+    if (b->ptr && b->cap > DEBIG_PIN_KEEP && b->cap / 4u > bytes) {
+        debig_hip_host_free(b->ptr);
+        b->ptr = NULL;
+        b->cap = 0;
+    }
     if (b->cap >= bytes && b->ptr) return 0;
     if (b->ptr) debig_hip_host_free(b->ptr);
     uint64_t cap = bytes + bytes / 4 + 4096;
@@ -155,22 +166,30 @@ int debig_upload_packed(debig_ctx *c, void *d_arena, const uint8_t *const *srcs,
     return rc;
 }
 
-int debig_download_unpack(debig_ctx *c, const void *d_arena, uint8_t *const *dsts, const uint64_t *sizes,
-                          const uint64_t *offs, uint32_t n, uint64_t total)
+/* last resort when no page-locked memory can be had: one synchronous copy per stream, straight into
+ * the caller's (pageable) buffers */
+static int download_direct(const void *d_arena, uint8_t *const *dsts, const uint64_t *sizes, const uint64_t *offs, uint32_t n)
 {
-    if (total == 0 || n == 0) return debig_hip_stream_sync(NULL);
-    if (pin_reserve(&c->pin_out, total)) return 2;
-    for (int k = 0; k < DEBIG_STAGE_CHUNKS; k++)
-        if (!c->ev[k] && !(c->ev[k] = debig_hip_event_create())) return 2;
-    uint64_t bytes = 0;
-    for (uint32_t i = 0; i < n; i++) bytes += sizes[i];
+    int rc = debig_hip_stream_sync(NULL);
+    for (uint32_t i = 0; i < n && !rc; i++)
+        if (sizes[i] && dsts[i]) rc = debig_hip_memcpy_d2h(dsts[i], (const uint8_t *)d_arena + offs[i], sizes[i], NULL);
+    if (!rc) rc = debig_hip_stream_sync(NULL);
+    return rc;
+}
+
+/* [0, total) of the pinned arena <- the same range of a device buffer, in DEBIG_STAGE_CHUNKS pieces;
+ * every piece is unpacked (memcpy to the callers' buffers, several threads) while the next ones are
+ * still on the wire.  offs: where each stream lies inside that range. */
+static int download_pieces(debig_ctx *c, const void *d_src, uint8_t *const *dsts, const uint64_t *sizes,
+                           const uint64_t *offs, uint32_t n, uint64_t total, uint64_t bytes)
+{
     /* pieces of equal size; a stream is unpacked with the piece that holds its LAST byte (the
      * copies are issued in order, so everything before it has landed as well) */
     const uint64_t step = (total + DEBIG_STAGE_CHUNKS - 1) / DEBIG_STAGE_CHUNKS;
     int rc = 0;
     for (int k = 0; k < DEBIG_STAGE_CHUNKS && !rc; k++) {
         const uint64_t lo = step * (uint64_t)k, hi = lo + step < total ? lo + step : total;
-        if (lo < hi) rc = debig_hip_memcpy_d2h((uint8_t *)c->pin_out.ptr + lo, (const uint8_t *)d_arena + lo, hi - lo, NULL);
+        if (lo < hi) rc = debig_hip_memcpy_d2h((uint8_t *)c->pin_out.ptr + lo, (const uint8_t *)d_src + lo, hi - lo, NULL);
         if (!rc) rc = debig_hip_event_record(c->ev[k], NULL);
     }
     copy_job j;
@@ -185,6 +204,56 @@ int debig_download_unpack(debig_ctx *c, const void *d_arena, uint8_t *const *dst
         j.arena_hi = j.arena_lo + step;
         if (!rc) run_copy(j, n, bytes / DEBIG_STAGE_CHUNKS);
     }
+    return rc;
+}
+
+/* Bring n decoded ranges [offs[i], offs[i] + sizes[i]) of a device arena of `total` bytes to the
+ * callers' buffers.  The arena is laid out by recipient CAPACITIES, the ranges are what was decoded:
+ *   dense arena  (the ranges fill at least half of it): the span goes over the wire as it is;
+ *   sparse arena (2048 streams with 1 MiB recipients that decode to 64 KiB: 2 GiB of span for
+ *                 128 MiB of data): the ranges are first packed on the device (debig_hip_gather, a
+ *                 copy list) and only the packed bytes cross PCIe and take pinned memory.
+ * No page-locked memory: one copy per stream into the pageable buffers instead of failing the batch. */
+int debig_download_unpack(debig_ctx *c, const void *d_arena, uint8_t *const *dsts, const uint64_t *sizes,
+                          const uint64_t *offs, uint32_t n, uint64_t total)
+{
+    if (total == 0 || n == 0) return debig_hip_stream_sync(NULL);
+    for (int k = 0; k < DEBIG_STAGE_CHUNKS; k++)
+        if (!c->ev[k] && !(c->ev[k] = debig_hip_event_create())) return 2;
+    uint64_t bytes = 0;
+    for (uint32_t i = 0; i < n; i++) bytes += dsts[i] ? sizes[i] : 0;
+    if (bytes == 0) return debig_hip_stream_sync(NULL);
+    if (bytes >= total / 2u) { /* dense */
+        if (pin_reserve(&c->pin_out, total)) return download_direct(d_arena, dsts, sizes, offs, n);
+        return download_pieces(c, d_arena, dsts, sizes, offs, n, total, bytes);
+    }
+    /* sparse: pack on the device */
+    debig_copy *list = (debig_copy *)malloc((size_t)n * sizeof(debig_copy));
+    uint64_t *dense_offs = (uint64_t *)malloc((size_t)n * sizeof(uint64_t));
+    int rc = (list && dense_offs) ? 0 : 2;
+    uint64_t at = 0;
+    uint32_t m = 0;
+    if (!rc) {
+        for (uint32_t i = 0; i < n; i++) {
+            dense_offs[i] = at;
+            if (!dsts[i] || !sizes[i]) continue;
+            list[m].src_off = offs[i];
+            list[m].dst_off = at;
+            list[m].len = sizes[i];
+            m++;
+            at += (sizes[i] + 15u) & ~(uint64_t)15; /* 16-byte aligned starts: aligned stores in the copy kernel */
+        }
+        if (debig_devbuf_reserve(&c->dense, at) || debig_devbuf_reserve(&c->dense_list, (uint64_t)m * sizeof(debig_copy)) ||
+            pin_reserve(&c->pin_out, at))
+            rc = 2;
+    }
+    if (!rc) rc = debig_hip_memcpy_h2d(c->dense_list.ptr, list, (uint64_t)m * sizeof(debig_copy), NULL);
+    if (!rc) rc = debig_hip_gather(d_arena, c->dense.ptr, (const debig_copy *)c->dense_list.ptr, m, NULL);
+    if (!rc) rc = debig_hip_stream_sync(NULL); /* `list` is pageable: the upload must be over before it is freed */
+    if (!rc) rc = download_pieces(c, c->dense.ptr, dsts, sizes, dense_offs, n, at, bytes);
+    free(list);
+    free(dense_offs);
+    if (rc == 2) return download_direct(d_arena, dsts, sizes, offs, n); /* out of (pinned / device) memory */
     return rc;
 }
 

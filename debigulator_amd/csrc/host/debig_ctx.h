@@ -20,6 +20,7 @@ typedef struct debig_ctx {
     debig_devbuf files, spans, crcs, copies; /* PNG: whole files, chunk spans, their CRCs, IDAT gather list */
     debig_devbuf ws; /* token workspace of the scan / LZ77 kernel pair (DEBIG_WAVES_SPLIT) */
     debig_devbuf pin_in, pin_out; /* page-locked staging arenas (host memory) */
+    debig_devbuf dense, dense_list; /* sparse downloads: the decoded ranges packed on the device first */
     void *ev[DEBIG_STAGE_CHUNKS]; /* download pipeline events */
 } debig_ctx;
 

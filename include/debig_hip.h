@@ -139,8 +139,20 @@ int debig_hip_inflate_batch_ex(const void *d_in, void *d_out, const debig_stream
                                debig_result *d_results, uint32_t n, uint32_t waves_per_stream,
                                void *hip_stream);
 
-/* Same with caller-owned workspace for DEBIG_WAVES_SPLIT (no allocation inside the call: safe to
- * capture into a hipGraph).  debig_hip_inflate_workspace_bytes() is the size that lets ordinary
+/* One-time set-up of the stream's device: the fixed-Huffman table images every inflate call reads
+ * (three small allocations, three tiny kernels, one synchronisation of `hip_stream`).  Calls do it
+ * lazily on first use; call it yourself BEFORE capturing a stream into a hipGraph -- allocations and
+ * synchronisation are illegal during capture.  Thread safe, idempotent.  0 or a hipError_t. */
+int debig_hip_init(void *hip_stream);
+
+/* Concurrency: calls on different streams or from different host threads are safe.  Callers that
+ * bring no workspace share ONE cached buffer per device: their groups of launches are serialised
+ * on it (each group waits for the event of the group before it), so concurrent callers that want
+ * overlap on the device should bring their own workspace.
+ *
+ * Same with caller-owned workspace for DEBIG_WAVES_SPLIT (no allocation inside the call once
+ * debig_hip_init() has run on the device: safe to capture into a hipGraph).
+ * debig_hip_inflate_workspace_bytes() is the size that lets ordinary
  * data through the scan/LZ77 pair (about 9 x the compressed bytes of the largest group of 16384
  * streams + 24 KiB per stream); less is legal and only sends more streams down the one-kernel
  * path.  d_workspace = NULL: the internal cached workspace.  The workspace holds no state between

@@ -62,6 +62,35 @@ def test_inflate_batch_big_batch_with_a_few_large_streams(api):
             assert out == plain.tobytes(), i
 
 
+def test_inflate_batch_with_oversized_recipients_downloads_only_what_was_decoded(api):
+    """csrc/host/debig_ctx.c: debig_download_unpack.  The device output arena is laid out by the
+    recipients' capacities; 300 streams that decode to 20 KB into 1 MiB recipients leave it 98 % empty,
+    so the decoded ranges are packed on the device (debig_hip_gather) before they cross PCIe.  One
+    failing stream and one empty-output stream ride along; every byte must still be right, and bytes
+    beyond final_recipient_size must not be touched in the callers' buffers."""
+    from debigulator_amd import workload
+
+    pairs = [workload.make_stream(("dynamic", "fixed", "stored")[i % 3], 50 + i, 20000) for i in range(300)]
+    datas = [bytes(p[0]) for p in pairs]
+    caps = [1 << 20] * len(pairs)
+    bad = bytearray(datas[5]); bad[len(bad) // 2] ^= 0x40
+    datas[5] = bytes(bad)
+    res = api.inflate_batch(datas, caps)
+    n_ok = 0
+    for i, ((good, final, out), (_, plain)) in enumerate(zip(res, pairs)):
+        if i == 5:
+            continue
+        assert good == 1 and final == len(plain), i
+        assert out == plain.tobytes(), i
+        n_ok += 1
+    assert n_ok == len(pairs) - 1
+    # dense layout right behind it on the same thread id (the arenas are reused)
+    res = api.inflate_batch(datas[:40], [max(len(p[1]) + 1, len(p[0])) for p in pairs[:40]])  # Q1: recipient >= input
+    for i, ((good, final, out), (_, plain)) in enumerate(zip(res, pairs[:40])):
+        if i != 5:
+            assert good == 1 and out == plain.tobytes(), i
+
+
 def test_inflate_batch_skewed_sizes_are_dispatched_longest_first(api):
     """A batch of 600 streams in which a quarter is large goes through debig_plan_batch
     (descriptors launched longest first, 4 wavefronts wide, results returned in the caller's

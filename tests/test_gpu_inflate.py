@@ -412,6 +412,7 @@ def test_batch_call_with_caller_workspace_is_graph_capturable(gpu_device):
                          (0x20, workload.make_streams("dynamic", 6, 3 << 20))):
         raws = [p[0] for p in pairs]
         b = DeviceBatch.from_streams(raws, [len(p[1]) for p in pairs], device=gpu_device)
+        assert b.lib.debig_hip_init(None) == 0  # the table images: nothing is left to allocate inside a call
         b.launch(waves_per_stream=width)  # allocates the batch's workspace, outside the capture
         torch.cuda.synchronize()
         s = torch.cuda.Stream(device=gpu_device)
@@ -431,6 +432,56 @@ def test_batch_call_with_caller_workspace_is_graph_capturable(gpu_device):
             assert (res["good"] == 1).all(), width
             for i in (0, len(pairs) // 2, len(pairs) - 1):
                 assert b.output(i, res) == pairs[i][1].tobytes(), (width, i)
+
+
+def test_default_workspace_is_safe_for_concurrent_callers(gpu_device):
+    """include/debig_hip.h: callers that bring no workspace share one cached buffer per device; their
+    groups of launches (plan, scan, lz, retry) are serialised on it.  Two host threads on two HIP
+    streams hammer debig_hip_inflate_batch_ex (scan / LZ77 pair, internal workspace) with different
+    batches at the same time: every stream of every round must still come out right."""
+    import ctypes as C
+    import threading
+
+    import torch
+
+    batches, plains = [], []
+    for kind, seed0 in (("fixed", 100), ("dynamic", 300)):
+        pairs = [workload.make_stream(kind, seed0 + i, 20000) for i in range(1200)]
+        batches.append(DeviceBatch.from_streams([p[0] for p in pairs], [len(p[1]) + 1 for p in pairs], device=gpu_device))
+        plains.append([p[1].tobytes() for p in pairs])
+    lib = batches[0].lib
+    assert lib.debig_hip_init(None) == 0
+    streams = [torch.cuda.Stream(device=gpu_device) for _ in batches]
+    errors = []
+
+    def hammer(k):
+        b, s = batches[k], streams[k]
+        try:
+            for _ in range(12):
+                rc = lib.debig_hip_inflate_batch_ex(b.d_in.data_ptr(), b.d_out.data_ptr(), b.d_streams.data_ptr(),
+                                                    b.d_results.data_ptr(), b.n, 0x10, C.c_void_p(s.cuda_stream))
+                if rc:
+                    errors.append((k, rc))
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    for rnd in range(3):
+        for b in batches:
+            b.d_out.zero_()
+            b.d_results.zero_()
+        torch.cuda.synchronize()
+        ts = [threading.Thread(target=hammer, args=(k,)) for k in range(len(batches))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        torch.cuda.synchronize()
+        assert not errors, errors
+        for b, want in zip(batches, plains):
+            res = b.results()
+            assert (res["good"] == 1).all(), rnd
+            for i in range(0, b.n, 37):
+                assert b.output(i, res) == want[i], (rnd, i)
 
 
 def test_invalid_width_is_rejected(gpu_device):
