@@ -57,25 +57,42 @@ def pack_streams(raws, caps, in_align=16, out_align=16, in_skew=0, out_skew=0, p
     return in_arena, streams, _align(out_off, 16) + 64
 
 
-def plan_batch(streams):
-    """Dispatch plan of one launch, the same rule as csrc/host/debig_ctx.h: debig_plan_batch.
-    A batch of at most 1024 streams with 1 MiB of input or more per stream on average goes through
-    the chunk-parallel path.  Workgroups start in descriptor order; a batch of 513..1024 streams whose largest quarter
-    holds at least half of the input bytes is launched longest first, 4 wavefronts wide.
-    -> (order or None, waves_per_stream or 0)."""
+LARGE_IN_BYTES = 256 << 10  # include/debig_hip.h: DEBIG_LARGE_IN_BYTES
+LARGE_OUT_BYTES = 1 << 20   # DEBIG_LARGE_OUT_BYTES
+WAVES_LARGE4_SMALL1 = 0x41  # DEBIG_WAVES_LARGE4_SMALL1
+
+
+def pick_waves(streams):
+    """csrc/host/debig_ctx.h: debig_pick_waves, line for line.  0 = the library's own choice from the
+    batch size (8 / 4 / 2 wavefronts per stream up to 256 / 512 / 1024 streams, the scan + LZ77 pair
+    beyond), which is what the C rule returns in those cases."""
     n = len(streams)
     lens = streams["in_len"].astype(np.int64)
-    if 0 < n <= 1024 and int(lens.sum()) >= n << 20:  # few streams, >= 1 MiB of input each on average
-        return None, N.WAVES_CHUNKED                   # debig_ctx.h: debig_pick_waves
-    if 1024 < n <= 16384 and int(lens.max()) >= 4 << 20:  # thousands of streams, a very large one among them
-        return None, N.WAVES_CHUNKED
-    if n <= 512 or n > 1024:
-        return None, 0
+    if n <= 1024:
+        if n and int(lens.sum()) >= n << 20:  # few streams, >= 1 MiB of input each on average
+            return N.WAVES_CHUNKED
+        return 0
+    n_large = int(((lens >= LARGE_IN_BYTES) | (streams["out_cap"].astype(np.int64) >= LARGE_OUT_BYTES)).sum())
+    if int(lens.max()) >= 4 << 20 and n <= 16384:  # thousands of streams, a very large one among them
+        return N.WAVES_CHUNKED
+    return WAVES_LARGE4_SMALL1 if 0 < n_large <= 256 else 0
+
+
+def plan_batch(streams):
+    """Dispatch plan of one launch, the same rule as csrc/host/debig_ctx.h: debig_plan_batch.
+    Chunk tasks when pick_waves says so (never reordered); workgroups start in descriptor order, so a
+    batch of 513..1024 streams whose largest quarter holds at least half of the input bytes is
+    launched longest first, 4 wavefronts wide.  -> (order or None, waves_per_stream or 0)."""
+    n = len(streams)
+    waves = pick_waves(streams)
+    if waves == N.WAVES_CHUNKED or n <= 512 or n > 1024:
+        return None, waves
+    lens = streams["in_len"].astype(np.int64)
     order = np.lexsort((np.arange(n), -lens))
     total, top = int(lens.sum()), int(lens[order[: n // 4]].sum())
     if total and top * 2 >= total:
         return order, 4
-    return None, 0
+    return None, waves
 
 
 class DeviceBatch:
@@ -154,13 +171,17 @@ class DeviceBatch:
             groups.append((first, self.n - first))
             biggest = max(biggest, need(tin, tout, self.n - first))
             self.chunk_groups = groups
-            self.d_ws_chunked = torch.empty(biggest, dtype=torch.uint8, device=self.device)
+            try:
+                self.d_ws_chunked = torch.empty(biggest, dtype=torch.uint8, device=self.device)
+            except RuntimeError:  # out of device memory: the library falls back to whole workgroups per stream
+                self.d_ws_chunked = None
         ssz, rsz = STREAM_DTYPE.itemsize, RESULT_DTYPE.itemsize
         for first, count in self.chunk_groups:
             rc = self.lib.debig_hip_inflate_batch_ws(self.d_in.data_ptr(), self.d_out.data_ptr(),
                                                      self.d_streams.data_ptr() + first * ssz,
                                                      self.d_results.data_ptr() + first * rsz, count, N.WAVES_CHUNKED,
-                                                     self.d_ws_chunked.data_ptr(), self.d_ws_chunked.numel(),
+                                                     self.d_ws_chunked.data_ptr() if self.d_ws_chunked is not None else None,
+                                                     self.d_ws_chunked.numel() if self.d_ws_chunked is not None else 0,
                                                      C.c_void_p(stream.cuda_stream))
             N.check(rc, "debig_hip_inflate_batch_ws")
 

@@ -451,6 +451,11 @@ int debig_hip_device_count(void)
     return n;
 }
 int debig_hip_set_device(int dev) { return (int)hipSetDevice(dev); }
+int debig_hip_get_device(void)
+{
+    int dev = -1;
+    return hipGetDevice(&dev) == hipSuccess ? dev : -1;
+}
 void *debig_hip_malloc(uint64_t bytes)
 {
     void *p = nullptr;

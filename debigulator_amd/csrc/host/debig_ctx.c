@@ -29,9 +29,10 @@ static void buf_free(debig_devbuf *b)
     b->cap = 0;
 }
 
-void debig_ctx_release(uint32_t thread_id)
+void debig_ctx_release(uint32_t thread_id) { debig_ctx_release_ptr(debig_ctx_get(thread_id)); }
+
+void debig_ctx_release_ptr(debig_ctx *c)
 {
-    debig_ctx *c = debig_ctx_get(thread_id);
     if (!c) return;
     buf_free(&c->in);
     buf_free(&c->out);

@@ -28,6 +28,7 @@ debig_ctx *debig_ctx_get(uint32_t thread_id);
 /* make sure b holds at least `bytes` (contents are not preserved); 0 on success */
 int debig_devbuf_reserve(debig_devbuf *b, uint64_t bytes);
 void debig_ctx_release(uint32_t thread_id);
+void debig_ctx_release_ptr(debig_ctx *c); /* every device buffer, pinned arena and event of one context */
 
 static inline uint64_t debig_align16(uint64_t x) { return (x + 15u) & ~(uint64_t)15u; }
 
@@ -99,6 +100,7 @@ static inline uint32_t debig_plan_batch(const debig_stream *desc, uint32_t n, ui
 {
     *permuted = 0;
     const uint32_t waves = debig_pick_waves(desc, n);
+    if (waves == DEBIG_WAVES_CHUNKED) return waves; /* chunk tasks are balanced by construction: no reordering */
     if (n <= 512u || n > 1024u || !order) return waves;
     debig_len_idx *v = (debig_len_idx *)malloc((size_t)n * sizeof(debig_len_idx));
     if (!v) return waves;

@@ -150,6 +150,14 @@ DEBIG_API uint32_t debig_shard_round_robin(uint32_t n, uint32_t n_devices, uint3
 #include <pthread.h>
 #define DEBIG_MAX_DEVICES 16
 static debig_ctx g_dev_ctx[DEBIG_MAX_DEVICES]; /* one context per device for the multi-device call */
+static pthread_mutex_t g_multi_lock = PTHREAD_MUTEX_INITIALIZER; /* the contexts serve one multi call at a time */
+/* DEBIG_MULTI_ONE_DEVICE=1 (rehearsal on a one-GPU machine): every worker thread and its context use
+ * device 0, so n_devices may exceed the GPUs present; the sharding and the threading are the real ones */
+static int multi_one_device(void)
+{
+    const char *e = getenv("DEBIG_MULTI_ONE_DEVICE");
+    return e && *e && *e != '0';
+}
 
 typedef struct multi_job {
     uint32_t device, n_devices, n;
@@ -182,7 +190,7 @@ static void *multi_worker(void *arg)
         sizes[k] = j->in_sizes[i];
         finals[k] = j->finals[i];
     }
-    if (!j->rc) j->rc = debig_hip_set_device((int)j->device); /* per-thread current device */
+    if (!j->rc) j->rc = debig_hip_set_device(multi_one_device() ? 0 : (int)j->device); /* per-thread current device */
     if (!j->rc) j->rc = inflate_batch_ctx(&g_dev_ctx[j->device], outs, caps, finals, ins, sizes, goods, m, NULL);
     for (uint32_t k = 0, i = j->device; k < m; k++, i += j->n_devices) {
         j->goods[i] = j->rc ? 0u : goods[k];
@@ -196,11 +204,15 @@ DEBIG_API int debig_inflate_batch_multi(uint8_t *const *outs, const uint64_t *ou
                                         const uint8_t *const *ins, const uint64_t *in_sizes, uint32_t *goods,
                                         uint32_t n, uint32_t n_devices)
 {
+    if (!goods) return 1; /* hipErrorInvalidValue */
     for (uint32_t i = 0; i < n; i++) goods[i] = 0;
     if (n == 0) return 0;
+    if (!outs || !out_caps || !finals || !ins || !in_sizes) return 1; /* the single-device call's NULL gates, for the arrays */
     const int have = debig_hip_device_count();
     if (n_devices == 0) n_devices = have > 0 ? (uint32_t)have : 0;
-    if (n_devices == 0 || n_devices > DEBIG_MAX_DEVICES || (int)n_devices > have) return 101; /* hipErrorInvalidDevice */
+    if (n_devices == 0 || n_devices > DEBIG_MAX_DEVICES || ((int)n_devices > have && !multi_one_device())) return 101; /* hipErrorInvalidDevice */
+    const int caller_dev = debig_hip_get_device();
+    pthread_mutex_lock(&g_multi_lock);
     multi_job jobs[DEBIG_MAX_DEVICES];
     pthread_t th[DEBIG_MAX_DEVICES];
     uint32_t started = 0;
@@ -217,8 +229,24 @@ DEBIG_API int debig_inflate_batch_multi(uint8_t *const *outs, const uint64_t *ou
         if (started & (1u << d)) pthread_join(th[d], NULL);
         if (jobs[d].rc && !rc) rc = jobs[d].rc;
     }
-    (void)debig_hip_set_device(0);
+    pthread_mutex_unlock(&g_multi_lock);
+    if (caller_dev >= 0) (void)debig_hip_set_device(caller_dev); /* the last share ran on the calling thread */
     return rc;
+}
+
+/* give back what debig_inflate_batch_multi keeps between calls: per device the device buffers, the
+ * token workspace, the page-locked arenas */
+DEBIG_API void debig_inflate_batch_multi_release(void)
+{
+    const int caller_dev = debig_hip_get_device();
+    pthread_mutex_lock(&g_multi_lock);
+    const int have = debig_hip_device_count();
+    for (int d = 0; d < DEBIG_MAX_DEVICES; d++) {
+        if (d < have && !multi_one_device()) (void)debig_hip_set_device(d);
+        debig_ctx_release_ptr(&g_dev_ctx[d]);
+    }
+    pthread_mutex_unlock(&g_multi_lock);
+    if (caller_dev >= 0) (void)debig_hip_set_device(caller_dev);
 }
 
 DEBIG_API void debig_inflate(uint8_t const *recipient, const uint64_t recipient_size, uint64_t *final_recipient_size,

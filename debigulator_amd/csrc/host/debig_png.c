@@ -285,6 +285,7 @@ DEBIG_API int debig_decode_png_batch(const uint8_t *const *inputs, const uint64_
             out_total += debig_align16(P[i].est) + 16 + 768; /* + room for the palette */
             rgba_total += debig_align16(out_sizes[i]) + 16;
             if (P[i].ct == 2 && !strict) rgba_total += debig_align16(out_sizes[i]) + 16; /* P3 replay: second buffer */
+            if (P[i].ct == 3 && P[i].w > 16384u) rgba_total += debig_align16(P[i].w) + 32; /* wide palette rows: index-row scratch */
         }
     }
     {
@@ -398,6 +399,10 @@ done_bulk:
             im->tmp_off = rgba_off;
             rgba_off += debig_align16(out_sizes[i]) + 16;
             if (!rc) rc = debig_hip_memcpy_h2d((uint8_t *)c->rgba.ptr + im->rgba_off, outs[i], out_sizes[i], NULL);
+        }
+        if (P[i].ct == 3 && P[i].w > 16384u) { /* include/debig_hip.h: debig_png_image.tmp_off for wide palette rows */
+            im->tmp_off = rgba_off;
+            rgba_off += debig_align16(P[i].w) + 32;
         }
         map[nimg++] = i;
     }

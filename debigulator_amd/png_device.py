@@ -59,6 +59,9 @@ class DevicePngBatch:
             img[i].width, img[i].height, img[i].color_type, img[i].asserts_off = it["w"], it["h"], it["ct"], 0
             self.rgba_off.append(off)
             off += (4 * it["w"] * it["h"] + 31) // 16 * 16
+            if it["ct"] == 3 and it["w"] > 16384:  # include/debig_hip.h: index-row scratch of wide palette images
+                img[i].tmp_off = off
+                off += (it["w"] + 47) // 16 * 16
             if it["palette"] is not None:
                 self.inflate.d_out[pal_base + 768 * i: pal_base + 768 * (i + 1)] = torch.from_numpy(it["palette"]).to(device)
         self.rgba_bytes = sum(4 * it["w"] * it["h"] for it in self.items)

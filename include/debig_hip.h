@@ -178,6 +178,9 @@ typedef struct debig_png_image {
      * for bit (its RGB->RGBA expansion runs inside the row loop): rgba_off
      * must then hold the caller's PRIOR buffer contents and tmp_off a second 4*w*h byte
      * buffer (relative to d_rgba_arena).  replay_p3 = 0: spec-conforming RGB -> RGBA. */
+    /* colour type 3 only: rows wider than 16384 pixels need width + 16 bytes of scratch at tmp_off
+     * (relative to d_rgba_arena, 4-byte aligned, not 0): the index row handed from one band of 64
+     * rows to the next; narrower palette images keep that row in LDS and ignore tmp_off. */
     uint64_t tmp_off;
     uint32_t replay_p3;
     uint32_t reserved;
@@ -222,6 +225,7 @@ int debig_hip_gather(const void *d_src_arena, void *d_dst_arena, const debig_cop
 /* plain device-to-device helpers used by the host layer (no torch needed) */
 int debig_hip_device_count(void);
 int debig_hip_set_device(int dev);
+int debig_hip_get_device(void); /* the calling thread's current device, -1 on error */
 void *debig_hip_malloc(uint64_t bytes);
 void debig_hip_free(void *p);
 int debig_hip_memcpy_h2d(void *d, const void *h, uint64_t bytes, void *hip_stream);

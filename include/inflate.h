@@ -64,6 +64,10 @@ uint32_t debig_shard_round_robin(uint32_t n, uint32_t n_devices, uint32_t device
 int debig_inflate_batch_multi(uint8_t *const *outs, const uint64_t *out_caps, uint64_t *finals,
                               const uint8_t *const *ins, const uint64_t *in_sizes, uint32_t *goods,
                               uint32_t n, uint32_t n_devices);
+/* One call at a time (concurrent calls are serialised inside); the calling thread's current device is
+ * left as it was; a NULL array returns hipErrorInvalidValue.  The per-device buffers are kept between
+ * calls: debig_inflate_batch_multi_release() gives them back. */
+void debig_inflate_batch_multi_release(void);
 
 #ifdef __cplusplus
 }

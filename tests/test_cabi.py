@@ -213,7 +213,10 @@ def test_dispatch_plan_rules():
     assert plan_batch(streams([2 << 20] * 64)) == (None, N.WAVES_CHUNKED)
     assert plan_batch(streams([400 << 10] * 256)) == (None, 0)                  # 0.4 MiB on average: workgroups
     assert plan_batch(streams([20000] * 2000 + [8 << 20])) == (None, N.WAVES_CHUNKED)
-    assert plan_batch(streams([20000] * 2000 + [1 << 20])) == (None, 0)
+    assert plan_batch(streams([20000] * 2000 + [1 << 20])) == (None, 0x41)    # a few large among thousands: those 4-wide
+    assert plan_batch(streams([20000] * 2000 + [100000])) == (None, 0)
+    # 513..1024 skewed streams that are also >= 1 MiB on average: chunk tasks win, no reordering (as in C)
+    assert plan_batch(streams([200 << 10] * 600 + [6 << 20] * 200)) == (None, N.WAVES_CHUNKED)
     assert plan_batch(streams([65536] * 8192)) == (None, 0)
     order, waves = plan_batch(streams([1000] * 600 + [500000] * 200))
     assert waves == 4 and list(order[:3]) == [600, 601, 602]

@@ -225,6 +225,34 @@ def test_decode_png_rgb_p3_depends_on_prior_buffer_like_the_reference(api, oracl
     assert g3 == 1
 
 
+def test_decode_png_very_wide_rows(api, oracle, gpu_device):
+    """No width limits (the reference has none, src/decode_png.c:1512-1564): a palette image 20 000
+    pixels wide (its index row no longer fits the de-filter kernel's LDS row: it is handed from band to
+    band through device scratch) and an RGB image 5 000 pixels wide through the colour-type-2 replay
+    (rows go through the LDS in pieces), against the oracle; the palette image also through the
+    device-resident batch class."""
+    from debigulator_amd.png_device import DevicePngBatch
+
+    rng = np.random.default_rng(5)
+    pal = rng.integers(0, 256, 768, dtype=np.uint8)
+    png3, _ = workload.make_png(31, 20000, 131, ct=3, ftype=4, noise=3, enc="dynamic", palette=pal)
+    want_good, want = oracle.decode_png(png3)
+    assert want_good == 1
+    good, rgba = api.decode_png(png3, thread_id=4)
+    assert good == 1 and np.array_equal(rgba.reshape(-1), np.asarray(want).reshape(-1))
+    b = DevicePngBatch([png3], device=gpu_device)
+    b.launch()
+    res, ires = b.results()
+    assert (res["good"] == 1).all() and (ires["good"] == 1).all()
+    assert np.array_equal(b.rgba(0).reshape(-1), np.asarray(want).reshape(-1))
+    for ftype in (4, 3, 1):
+        png2, _ = workload.make_png(32 + ftype, 5000, 7, ct=2, ftype=ftype, noise=5, enc="fixed")
+        want_good, want = oracle.decode_png(png2)
+        good, rgba = api.decode_png(png2, thread_id=4)
+        assert good == want_good == 1, ftype
+        assert np.array_equal(rgba.reshape(-1), np.asarray(want).reshape(-1)), ftype
+
+
 def test_gzip_trailer_verification_on_gpu(api):
     """extension beyond the reference (which reads the CRC32/ISIZE trailer and ignores it,
     src/decode_gz.c:281-297): checked on the GPU against the decompressed bytes"""
@@ -352,7 +380,7 @@ def test_gunzip_batch_headers_members_and_trailers(api):
     assert gzip.decompress(files[2]) == want[2][1]
 
 
-def test_inflate_batch_multi_one_device_and_staging(api, oracle):
+def test_inflate_batch_multi_one_device_and_staging(api, oracle, monkeypatch):
     """debig_inflate_batch_multi (include/inflate.h) with n_devices = 1 (one worker thread, its own
     device context) and debig_inflate_batch over 3000 host-buffer streams: inputs go up in one
     transfer through the page-locked arena, outputs come down in pieces and are unpacked by host
@@ -398,6 +426,31 @@ def test_inflate_batch_multi_one_device_and_staging(api, oracle):
         else:
             assert finals[i] == f and outs[i][:f].tobytes() == o, i
     assert L.debig_inflate_batch_multi(out_ptrs, capsa, finals, in_ptrs, in_sizes, goods, n, 9) != 0  # no such device
+    assert L.debig_inflate_batch_multi(out_ptrs, capsa, None, in_ptrs, in_sizes, goods, n, 1) != 0  # NULL array: an error, no crash
+    # three worker threads, three device contexts, all on device 0 (DEBIG_MULTI_ONE_DEVICE: the rehearsal
+    # of the n_devices > 1 path on a one-GPU box): stream i is decoded by worker i mod 3
+    import torch
+
+    monkeypatch.setenv("DEBIG_MULTI_ONE_DEVICE", "1")
+    dev_before = torch.cuda.current_device()
+    for a in outs:
+        a[:] = 0
+    finals = (C.c_uint64 * n)(*([api.NOT_SET] * n))
+    goods = (C.c_uint32 * n)()
+    assert L.debig_inflate_batch_multi(out_ptrs, capsa, finals, in_ptrs, in_sizes, goods, n, 3) == 0
+    monkeypatch.delenv("DEBIG_MULTI_ONE_DEVICE")
+    assert torch.cuda.current_device() == dev_before
+    for i in range(n):
+        g, f, o = want[i]
+        if i == 17:
+            assert goods[i] == 0 and finals[i] == api.NOT_SET
+            continue
+        assert goods[i] == g, i
+        if f is not None:
+            assert finals[i] == f and outs[i][:f].tobytes() == o, i
+    L.debig_inflate_batch_multi_release.restype = None
+    L.debig_inflate_batch_multi_release()
+    assert L.debig_inflate_batch_multi(out_ptrs, capsa, finals, in_ptrs, in_sizes, goods, 50, 1) == 0  # and again after the release
 
 
 def test_large_streams_take_the_chunk_parallel_path_through_the_c_calls(api, monkeypatch):

@@ -1,5 +1,5 @@
 import os, sys, subprocess
-ROOT='/root/repo'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CHILD = r'''
 import os, sys
