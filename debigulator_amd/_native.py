@@ -63,6 +63,10 @@ def lib():
     L.debig_hip_inflate_batch.argtypes = [vp, vp, vp, vp, u32, vp]
     L.debig_hip_inflate_batch_ex.restype = C.c_int
     L.debig_hip_inflate_batch_ex.argtypes = [vp, vp, vp, vp, u32, u32, vp]
+    L.debig_hip_inflate_plan_ws.restype = C.c_int
+    L.debig_hip_inflate_plan_ws.argtypes = [vp, u32, vp, u64, vp]
+    L.debig_hip_inflate_planned_ws.restype = C.c_int
+    L.debig_hip_inflate_planned_ws.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp]
     L.debig_hip_init.restype = C.c_int
     L.debig_hip_init.argtypes = [vp]
     L.debig_hip_inflate_batch_ws.restype = C.c_int

@@ -144,6 +144,18 @@ class DeviceBatch:
                 nbytes = int(self.lib.debig_hip_inflate_workspace_bytes(total_in, self.n))
                 self.d_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             ws_ptr, ws_bytes = self.d_ws.data_ptr(), self.d_ws.numel()
+            if self.n <= 16384:
+                # the descriptors and the workspace are this object's own and never change: the workspace
+                # is carved once (debig_hip_inflate_plan_ws), every launch is scan + LZ77 only
+                if not getattr(self, "_planned", False):
+                    N.check(self.lib.debig_hip_inflate_plan_ws(self.d_streams.data_ptr(), self.n, ws_ptr, ws_bytes,
+                                                               C.c_void_p(stream.cuda_stream)), "debig_hip_inflate_plan_ws")
+                    self._planned = True
+                N.check(self.lib.debig_hip_inflate_planned_ws(self.d_in.data_ptr(), self.d_out.data_ptr(),
+                                                              self.d_streams.data_ptr(), self.d_results.data_ptr(), self.n,
+                                                              ws_ptr, ws_bytes, C.c_void_p(stream.cuda_stream)),
+                        "debig_hip_inflate_planned_ws")
+                return
         rc = self.lib.debig_hip_inflate_batch_ws(self.d_in.data_ptr(), self.d_out.data_ptr(),
                                                  self.d_streams.data_ptr(), self.d_results.data_ptr(),
                                                  self.n, waves_per_stream, ws_ptr, ws_bytes,

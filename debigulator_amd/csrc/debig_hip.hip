@@ -184,8 +184,11 @@ static DefaultWs *default_workspace(hipStream_t s)
 
 // one group of at most SPLIT_GROUP streams: plan, scan, lz, and debig_inflate_kernel for what the
 // pair handed back.  Returns 0, a hipError_t, or -1 when the workspace is too small to try.
+// what = 1: carve the workspace only (debig_split_plan_kernel), 2: scan + lz + hand-back over a
+// workspace already carved for exactly these descriptors, 3: both (one call does everything)
 static int launch_split_group(hipStream_t s, const void *d_in, void *d_out, const debig_stream *d_streams,
-                              debig_result *d_results, uint32_t n, const FixedTabs *tabs, void *ws, uint64_t ws_bytes)
+                              debig_result *d_results, uint32_t n, const FixedTabs *tabs, void *ws, uint64_t ws_bytes,
+                              int what = 3)
 {
     const uint64_t slots_bytes = align_up((uint64_t)n * sizeof(debig_ws_slot), 256);
     if (ws_bytes < slots_bytes + (uint64_t)n * 1024u) return -1;
@@ -196,7 +199,9 @@ static int launch_split_group(hipStream_t s, const void *d_in, void *d_out, cons
     debig_ws_slot *slots = (debig_ws_slot *)ws;
     debig_ws_rec *recs = (debig_ws_rec *)((uint8_t *)ws + slots_bytes);
     uint32_t *rows = (uint32_t *)((uint8_t *)ws + slots_bytes + recs_bytes);
-    hipLaunchKernelGGL(debig_split_plan_kernel, dim3(1), dim3(1024), 0, s, d_streams, n, slots, total_rows, total_recs);
+    if (what & 1)
+        hipLaunchKernelGGL(debig_split_plan_kernel, dim3(1), dim3(1024), 0, s, d_streams, n, slots, total_rows, total_recs);
+    if (!(what & 2)) return (int)hipGetLastError();
     hipLaunchKernelGGL(debig_scan_kernel, dim3(n), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, n,
                        tabs->scan, slots, recs, rows, d_results);
     hipLaunchKernelGGL(debig_lz_kernel, dim3(n), dim3(64), 0, s, (uint8_t *)d_out, d_streams, d_results, n,
@@ -374,6 +379,31 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
     if (rc) return rc;
     if ((e = hipStreamWaitEvent(s, l->join, 0)) != hipSuccess) return (int)e;
     return 0;
+}
+
+// ---- plan once, execute many times (DEBIG_WAVES_SPLIT, one group of streams)
+int debig_hip_inflate_plan_ws(const debig_stream *d_streams, uint32_t n, void *d_workspace, uint64_t workspace_bytes,
+                              void *hip_stream)
+{
+    if (n == 0) return 0;
+    if (n > SPLIT_GROUP || !d_workspace) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)hip_stream;
+    DeviceGuard launch_guard(launch_device(s));
+    int rc = launch_split_group(s, nullptr, nullptr, d_streams, nullptr, n, nullptr, d_workspace, workspace_bytes, 1);
+    return rc < 0 ? (int)hipErrorInvalidValue : rc;
+}
+
+int debig_hip_inflate_planned_ws(const void *d_in, void *d_out, const debig_stream *d_streams, debig_result *d_results,
+                                 uint32_t n, void *d_workspace, uint64_t workspace_bytes, void *hip_stream)
+{
+    if (n == 0) return 0;
+    if (n > SPLIT_GROUP || !d_workspace) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)hip_stream;
+    DeviceGuard launch_guard(launch_device(s));
+    const FixedTabs *ft = fixed_tables(s);
+    if (!ft) return (int)hipErrorOutOfMemory;
+    int rc = launch_split_group(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes, 2);
+    return rc < 0 ? (int)hipErrorInvalidValue : rc;
 }
 
 int debig_hip_init(void *hip_stream)

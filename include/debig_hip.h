@@ -165,6 +165,22 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
                                debig_result *d_results, uint32_t n, uint32_t waves_per_stream,
                                void *d_workspace, uint64_t workspace_bytes, void *hip_stream);
 
+/* DEBIG_WAVES_SPLIT in two steps, for callers that inflate batches with the SAME descriptors again
+ * and again (a decode loop over equal-sized buffers, a captured graph): the share of the workspace
+ * every stream gets depends on the descriptors only, so it can be carved once.
+ *   debig_hip_inflate_plan_ws     carves `d_workspace` for these n <= 16384 descriptors (one small
+ *                                 kernel: what debig_hip_inflate_batch_ws does first on every call);
+ *   debig_hip_inflate_planned_ws  scan + LZ77 (+ the one-kernel path for streams handed back) over a
+ *                                 workspace that plan_ws carved for exactly these descriptors, this n
+ *                                 and this workspace size and that nothing else has written since
+ *                                 (the kernels leave the plan intact: call it any number of times).
+ * Results are those of debig_hip_inflate_batch_ws.  n > 16384 or no workspace: hipErrorInvalidValue
+ * (such batches go through the workspace group by group: use debig_hip_inflate_batch_ws). */
+int debig_hip_inflate_plan_ws(const debig_stream *d_streams, uint32_t n, void *d_workspace, uint64_t workspace_bytes,
+                              void *hip_stream);
+int debig_hip_inflate_planned_ws(const void *d_in, void *d_out, const debig_stream *d_streams, debig_result *d_results,
+                                 uint32_t n, void *d_workspace, uint64_t workspace_bytes, void *hip_stream);
+
 /* One image for the de-filter kernel: the inflated scanline stream (filter byte
  * + w*bpp bytes per row) -> 4-channel RGBA. */
 typedef struct debig_png_image {

@@ -484,6 +484,49 @@ def test_default_workspace_is_safe_for_concurrent_callers(gpu_device):
                 assert b.output(i, res) == want[i], (rnd, i)
 
 
+def test_plan_once_execute_many(oracle, gpu_device):
+    """include/debig_hip.h: debig_hip_inflate_plan_ws carves the workspace for a set of descriptors,
+    debig_hip_inflate_planned_ws runs scan + LZ77 over it any number of times.  A roomy workspace and
+    one so small that most streams are handed to the one-kernel path; mixed block types, a damaged
+    stream; outputs cleared between the runs; every run must give the oracle's answers."""
+    import ctypes as C
+
+    import torch
+
+    rng = random.Random(2024)
+    raws, caps = [], []
+    for i in range(1500):
+        data = _payload(rng, rng.randint(100, 30000), rng.randint(0, 4))
+        raw = _zlib_raw(data, rng.choice([0, 1, 6]), rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED]), 9, rng.randint(0, 2), rng)
+        if i % 301 == 7:
+            raw = raw[: len(raw) // 2] + bytes(8)
+        raws.append(raw); caps.append(max(len(data) + 1, len(raw)))
+    exp = [oracle.inflate(r, c, want_stats=True) for r, c in zip(raws, caps)]
+    b = DeviceBatch.from_streams(raws, caps, device=gpu_device)
+    lib = b.lib
+    s = torch.cuda.current_stream()
+    total_in = sum(len(r) for r in raws)
+    for ws_bytes in (int(lib.debig_hip_inflate_workspace_bytes(total_in, b.n)), 3 << 20):
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=gpu_device)
+        assert lib.debig_hip_inflate_plan_ws(b.d_streams.data_ptr(), b.n, ws.data_ptr(), ws_bytes, C.c_void_p(s.cuda_stream)) == 0
+        for rnd in range(3):
+            b.d_out.zero_()
+            b.d_results.zero_()
+            assert lib.debig_hip_inflate_planned_ws(b.d_in.data_ptr(), b.d_out.data_ptr(), b.d_streams.data_ptr(),
+                                                    b.d_results.data_ptr(), b.n, ws.data_ptr(), ws_bytes,
+                                                    C.c_void_p(s.cuda_stream)) == 0
+            res = b.results()
+            host = b.outputs_host()
+            for i, (g, f, o, st) in enumerate(exp):
+                if st.ub_flags & UB_EXCLUDED:
+                    continue
+                assert res[i]["good"] == g, (ws_bytes, rnd, i)
+                if f is not None:
+                    off = int(b.streams_host[i]["out_off"])
+                    assert int(res[i]["final_size"]) == f and host[off:off + f].tobytes() == o, (ws_bytes, rnd, i)
+    assert lib.debig_hip_inflate_plan_ws(b.d_streams.data_ptr(), 20000, ws.data_ptr(), ws_bytes, None) != 0  # more than one group
+
+
 def test_invalid_width_is_rejected(gpu_device):
     pairs = workload.make_streams("fixed", 1, 4096)
     b = DeviceBatch.from_streams([pairs[0][0]], [8192], device=gpu_device)
