@@ -77,6 +77,8 @@ def parse_args():
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed even at N = 1")
     ap.add_argument("--no-cfg5", action="store_true", help="cfg2: skip the cfg5_strong record")
+    ap.add_argument("--no-kinds", action="store_true", help="cfg2: skip roofline_huffman / roofline_stored (profiling "
+                    "runs: the kernel statistics then hold whole-batch launches only)")
     ap.add_argument("--cfg5-steps", type=int, default=3, help="timed steps of the cfg5_strong record")
     args = ap.parse_args()
     if args.steps is None:
@@ -488,7 +490,7 @@ def main():
             return res
 
         # each kind alone (its own descriptors over the same arenas would change nothing: own batch)
-        for kind, lo in (("fixed", 0), ("stored", per)):
+        for kind, lo in (() if args.no_kinds else (("fixed", 0), ("stored", per))):
             kinds[kind] = (DeviceBatch.from_streams(raws[lo:lo + per], caps[lo:lo + per], device=dev),
                            c_kind[kind], per * STREAM_BYTES)
         workload_name = (f"cfg2: per GPU {per} fixed-Huffman + {per} stored DEFLATE streams, 64 KiB each, one "

@@ -202,10 +202,18 @@ static int launch_split_group(hipStream_t s, const void *d_in, void *d_out, cons
     if (what & 1)
         hipLaunchKernelGGL(debig_split_plan_kernel, dim3(1), dim3(1024), 0, s, d_streams, n, slots, total_rows, total_recs);
     if (!(what & 2)) return (int)hipGetLastError();
+#ifndef DEBIG_SPLIT_FUSED
+#define DEBIG_SPLIT_FUSED 1
+#endif
+#if DEBIG_SPLIT_FUSED
+    hipLaunchKernelGGL(debig_scanlz_kernel, dim3(n), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, n,
+                       tabs->scan, slots, recs, rows, d_results);
+#else
     hipLaunchKernelGGL(debig_scan_kernel, dim3(n), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, n,
                        tabs->scan, slots, recs, rows, d_results);
     hipLaunchKernelGGL(debig_lz_kernel, dim3(n), dim3(64), 0, s, (uint8_t *)d_out, d_streams, d_results, n,
                        (const debig_ws_slot *)slots, (const debig_ws_rec *)recs, (const uint32_t *)rows);
+#endif
     hipLaunchKernelGGL(debig_inflate_kernel, dim3(n), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams,
                        d_results, n, tabs->one, DEBIG_CLASS_RETRY);
     return (int)hipGetLastError();

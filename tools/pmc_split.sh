@@ -2,9 +2,9 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 K=${1:-fixed}
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM --output-format csv -d $R/gpurun_out/pmcs_a_$K -- python3 $R/tools/bench_variant.py $K 4096 0x10 > $R/gpurun_out/pmcs_a_$K.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $R/gpurun_out/pmcs_b_$K -- python3 $R/tools/bench_variant.py $K 4096 0x10 > $R/gpurun_out/pmcs_b_$K.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH --output-format csv -d $R/gpurun_out/pmcs_c_$K -- python3 $R/tools/bench_variant.py $K 4096 0x10 > $R/gpurun_out/pmcs_c_$K.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM --output-format csv -d $R/gpurun_out/pmcs_a_$K -- python3 $R/tools/bench_variant.py $K 4096 0 > $R/gpurun_out/pmcs_a_$K.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $R/gpurun_out/pmcs_b_$K -- python3 $R/tools/bench_variant.py $K 4096 0 > $R/gpurun_out/pmcs_b_$K.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH --output-format csv -d $R/gpurun_out/pmcs_c_$K -- python3 $R/tools/bench_variant.py $K 4096 0 > $R/gpurun_out/pmcs_c_$K.log 2>&1
 cd $R
 python3 - <<PY
 import csv, glob, os

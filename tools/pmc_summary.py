@@ -16,7 +16,9 @@ for name in ("fetch", "write"):
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     # steps: split at every plan kernel (or every one-kernel launch when the plan kernel is absent)
     steps, cur = [], []
-    marker = "debig_split_plan_kernel" if any("debig_split_plan_kernel" in r["Kernel_Name"] for r in rows) else "debig_inflate_kernel"
+    # round 3: the workspace is carved once per batch object, a step is scan + lz + hand-back
+    marker = "debig_scan_kernel" if any("debig_scan_kernel" in r["Kernel_Name"] for r in rows) else "debig_inflate_kernel"
+    rows = [r for r in rows if "debig_split_plan_kernel" not in r["Kernel_Name"]]
     for r in rows:
         if marker in r["Kernel_Name"] and cur:
             steps.append(cur)
@@ -24,7 +26,7 @@ for name in ("fetch", "write"):
         cur.append(r)
     if cur:
         steps.append(cur)
-    # the bench also launches each stream kind alone (smaller grids): keep the whole-batch steps
+    # (older runs also launched each stream kind alone, smaller grids): keep the whole-batch steps
     big = max(max(int(r["Grid_Size"]) for r in st) for st in steps)
     steps = [st for st in steps if max(int(r["Grid_Size"]) for r in st) == big]
     last = steps[-3:]
@@ -38,19 +40,22 @@ for k, d in per_kernel.items():
     print(f"  {k:28s} FETCH_SIZE {d.get('fetch', 0):12.1f} KB raw   WRITE_SIZE {d.get('write', 0):12.1f} KB")
 if "fetch" in out and "write" in out:
     f, w = out["fetch"][0], out["write"][0]
-    # gfx950: FETCH_SIZE reports 1/2 of a WIDE coalesced read stream (MI355X_MICROARCH.md, HBM): that is
-    # the scan kernel (16 B/lane input staging, stored-block copies) and the one-kernel path; the LZ77
-    # kernel reads 4 B/lane token rows and 16-byte history gathers, for which the counter is taken as is
-    wide = sum(d.get("fetch", 0.0) for k, d in per_kernel.items() if "lz_kernel" not in k)
-    b = (f + wide + w) * 1024
-    print(f"HBM traffic ~= FETCH (x2 for the wide-read kernels) + WRITE = {b/1e6:.1f} MB per step "
-          f"(FETCH {f*1024/1e6:.1f} MB raw, of it {wide*1024/1e6:.1f} MB wide reads; WRITE {w*1024/1e6:.1f} MB)")
+    # gfx950: FETCH_SIZE tallies 64 bytes per 128-byte line request, for coalesced streams (MI355X_MICROARCH.md, HBM)
+    # and -- calibrated in round 3 with tools/ubench_fetch.hip, profiles/r03_fetch_calibration.txt -- for the LZ77
+    # kernel's shapes too: 4 B/lane token rows are reported at 1/2, a random 16-byte history gather is one line
+    # request and moves a whole 128-byte line.  HBM read bytes = 2 x FETCH_SIZE for every kernel.
+    wide = f
+    b = (2 * f + w) * 1024
+    print(f"HBM traffic ~= 2 x FETCH + WRITE = {b/1e6:.1f} MB per step (FETCH {f*1024/1e6:.1f} MB raw, WRITE {w*1024/1e6:.1f} MB)")
+    for k, d in per_kernel.items():
+        print(f"  {k:28s} reads {2*d.get('fetch', 0)*1024/1e6:9.1f} MB  writes {d.get('write', 0)*1024/1e6:9.1f} MB")
     from bench import kernel_sources_digest
     json.dump({"bytes_per_launch": b, "fetch_size_kb_raw": f, "write_size_kb": w,
                "per_kernel_kb_raw": per_kernel, "kernel_sources_sha256": kernel_sources_digest(),
                "source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py (tools/pmc_traffic.sh)",
                "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py "
-                      "(tools/pmc_traffic.sh), summed over the kernels of one whole-batch step; FETCH_SIZE doubled for the "
-                      "kernels whose reads are wide coalesced streams (gfx950 reports half of those: MI355X_MICROARCH.md, "
-                      "HBM), taken as is for the LZ77 kernel (4 B/lane token rows, 16-byte history gathers: uncalibrated)"},
+                      "(tools/pmc_traffic.sh), summed over the kernels of one whole-batch step; FETCH_SIZE doubled for every "
+                      "kernel: gfx950 tallies 64 bytes per 128-byte line request (MI355X_MICROARCH.md, HBM), calibrated for the "
+                      "LZ77 kernel's token rows and 16-byte history gathers with tools/ubench_fetch.hip "
+                      "(profiles/r03_fetch_calibration.txt)"},
               open("profiles/pmc_traffic.json", "w"), indent=1)

@@ -92,9 +92,13 @@ extern "C" int emu_inflate_split_batch(const void *in, void *out, const debig_st
     debig_ws_rec *recs = (debig_ws_rec *)(ws + slots_bytes);
     uint32_t *rows = (uint32_t *)(ws + slots_bytes + recs_bytes);
     EMU_LAUNCH(debig_split_plan_kernel, 1, EMU_PLAN_THREADS, streams, n, slots, total_rows, total_recs);
-    EMU_LAUNCH(debig_scan_kernel, n, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
-    EMU_LAUNCH(debig_lz_kernel, n, 64, (uint8_t *)out, streams, results, n, (const debig_ws_slot *)slots,
-               (const debig_ws_rec *)recs, (const uint32_t *)rows);
+    if (getenv("DEBIG_EMU_TWO_KERNELS")) { /* the two halves as separate kernels (the chunk path's shape) */
+        EMU_LAUNCH(debig_scan_kernel, n, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
+        EMU_LAUNCH(debig_lz_kernel, n, 64, (uint8_t *)out, streams, results, n, (const debig_ws_slot *)slots,
+                   (const debig_ws_rec *)recs, (const uint32_t *)rows);
+    } else {
+        EMU_LAUNCH(debig_scanlz_kernel, n, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
+    }
     uint32_t retried = 0;
     for (uint32_t i = 0; i < n; i++) retried += results[i].status == DEBIG_E_RETRY;
     if (n_retried) *n_retried = retried;
