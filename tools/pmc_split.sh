@@ -8,7 +8,7 @@ rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INST
 cd $R
 python3 - <<PY
 import csv, glob, os
-for kern in ("debig_scan_kernel", "debig_lz_kernel"):
+for kern in ("debig_scanlz_kernel", "debig_scan_kernel", "debig_lz_kernel"):
     print("==", kern)
     tot = {}
     for pas in "abc":

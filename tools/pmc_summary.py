@@ -17,7 +17,8 @@ for name in ("fetch", "write"):
     # steps: split at every plan kernel (or every one-kernel launch when the plan kernel is absent)
     steps, cur = [], []
     # round 3: the workspace is carved once per batch object, a step is scan + lz + hand-back
-    marker = "debig_scan_kernel" if any("debig_scan_kernel" in r["Kernel_Name"] for r in rows) else "debig_inflate_kernel"
+    marker = next((m for m in ("debig_scanlz_kernel", "debig_scan_kernel", "debig_inflate_kernel")
+                   if any(m in r["Kernel_Name"] for r in rows)), "debig_inflate_kernel")
     rows = [r for r in rows if "debig_split_plan_kernel" not in r["Kernel_Name"]]
     for r in rows:
         if marker in r["Kernel_Name"] and cur:
