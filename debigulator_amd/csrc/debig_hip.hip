@@ -389,6 +389,7 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
     return 0;
 }
 
+static DefaultWs *png_gsync(hipStream_t s, uint32_t n);
 // ---- plan once, execute many times (DEBIG_WAVES_SPLIT, one group of streams)
 int debig_hip_inflate_plan_ws(const debig_stream *d_streams, uint32_t n, void *d_workspace, uint64_t workspace_bytes,
                               void *hip_stream)
@@ -421,7 +422,9 @@ int debig_hip_init(void *hip_stream)
     // with a caller-owned workspace enqueues kernels and nothing else: capturable into a hipGraph.
     hipStream_t s = (hipStream_t)hip_stream;
     DeviceGuard launch_guard(launch_device(s));
-    return fixed_tables(s) ? 0 : (int)hipErrorOutOfMemory;
+    if (!fixed_tables(s)) return (int)hipErrorOutOfMemory;
+    (void)png_gsync(s, 1); /* the de-filter's progress counters (few-images mode) */
+    return 0;
 }
 
 int debig_hip_inflate_batch_ex(const void *d_in, void *d_out, const debig_stream *d_streams,
@@ -435,6 +438,25 @@ int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d
                             debig_result *d_results, uint32_t n, void *hip_stream)
 {
     return debig_hip_inflate_batch_ex(d_in, d_out, d_streams, d_results, n, 0, hip_stream);
+}
+
+// progress counters of the de-filter's several-workgroups-per-image mode: one cached allocation per
+// device (256 images at most take this path)
+static DefaultWs g_png_gsync[64]; /* shared by the callers of a device: uses are serialised (SharedWsUse) */
+static DefaultWs *png_gsync(hipStream_t s, uint32_t n)
+{
+    const int dev = launch_device(s);
+    if (dev < 0 || dev >= 64 || n > 256u) return nullptr;
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    DeviceGuard guard(dev);
+    DefaultWs *w = &g_png_gsync[dev];
+    if (!w->ptr) {
+        void *p = nullptr;
+        if (hipMalloc(&p, 256u * PNG_GSYNC_STRIDE * sizeof(uint32_t)) != hipSuccess) return nullptr;
+        w->ptr = p;
+        w->bytes = 256u * PNG_GSYNC_STRIDE * sizeof(uint32_t);
+    }
+    return w;
 }
 
 // Wavefronts per image for the de-filter (png_kernel.inc): few images -> several wavefronts each
@@ -464,6 +486,46 @@ int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena
     DeviceGuard launch_guard(launch_device((hipStream_t)hip_stream)); /* kernels go to the stream's device */
     const uint32_t nwd = defilter_waves(n);
     hipStream_t s = (hipStream_t)hip_stream;
+    // few images: an image on several workgroups (CUs).  G workgroups of 4 wavefronts per image; all of
+    // them must be resident together (87 KB of LDS: one per CU), so n * G stays within the CU count.
+    // DEBIG_DEFILTER_WGS = 1 turns it off, 2 / 4 / 8 force G (measurements).
+    {
+        static std::once_flag once;
+        static uint32_t env_g = 0, env_w = 0;
+        std::call_once(once, [] {
+            const char *e = getenv("DEBIG_DEFILTER_WGS");
+            if (e && *e) env_g = (uint32_t)strtoul(e, nullptr, 0);
+            e = getenv("DEBIG_DEFILTER_WG_WAVES"); /* 2 | 4 | 8 wavefronts per workgroup in that mode (measurements) */
+            if (e && *e) env_w = (uint32_t)strtoul(e, nullptr, 0);
+        });
+        // measured, 8192 x 8192 images (profiles/r03_defilter_wgs.txt): 32 images 43.6 -> 17.0 ms with 8 x 4
+        // wavefronts, 64 images 46.6 -> 25.4 with 4 x 4, 128 images 54.6 -> 36.2 with 2 x 8
+        uint32_t g = n <= 32u ? 8u : n <= 64u ? 4u : n <= 128u ? 2u : 1u;
+        uint32_t wpw = n <= 64u ? 4u : 8u;
+        if (env_g) g = env_g;
+        if (env_w == 2u || env_w == 4u || env_w == 8u) wpw = env_w;
+        if (g > 8u) g = 8u;
+        if (g * wpw > PNG_GSYNC_STRIDE - 16u) g = (PNG_GSYNC_STRIDE - 16u) / wpw; /* progress words per image */
+        DefaultWs *gw = g > 1u && (uint64_t)n * g <= 256u ? png_gsync(s, n) : nullptr;
+        if (gw) {
+            SharedWsUse hold(gw, s);
+            uint32_t *gsync = (uint32_t *)gw->ptr;
+            hipError_t e = hipMemsetAsync(gsync, 0, (size_t)n * PNG_GSYNC_STRIDE * sizeof(uint32_t), s);
+            if (e != hipSuccess) return (int)e;
+            if (wpw == 8u)
+                hipLaunchKernelGGL((debig_png_defilter_kernel<8, 16, true>), dim3(n * g), dim3(512), 0, s,
+                                   (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n, g, gsync);
+            else if (wpw == 2u)
+                hipLaunchKernelGGL((debig_png_defilter_kernel<2, 16, true>), dim3(n * g), dim3(128), 0, s,
+                                   (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n, g, gsync);
+            else
+                hipLaunchKernelGGL((debig_png_defilter_kernel<4, 16, true>), dim3(n * g), dim3(256), 0, s,
+                                   (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n, g, gsync);
+            hipLaunchKernelGGL(debig_png_p3_kernel, dim3(n), dim3(PNG_P3_THREADS), 0, s,
+                               (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n);
+            return (int)hipGetLastError();
+        }
+    }
 #define DEFILTER_LAUNCH(W)                                                                              \
     hipLaunchKernelGGL(debig_png_defilter_kernel<W>, dim3(n), dim3(64 * W), 0, s, (const uint8_t *)d_streams_arena, \
                        (uint8_t *)d_rgba_arena, d_images, d_results, n)

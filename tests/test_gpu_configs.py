@@ -98,6 +98,50 @@ def test_cfg4_one_full_size_image(gpu_device):
     assert np.array_equal(b.rgba(0).reshape(side, side * 4), np.asarray(pix).reshape(side, side * 4))
 
 
+@pytest.mark.parametrize("n", [5, 40, 100])
+def test_defilter_several_workgroups_per_image(gpu_device, oracle, n):
+    """Few images: the de-filter spreads one image over several workgroups (csrc/png_kernel.inc, MWG:
+    8 x 4 wavefronts per image up to 32 images, 4 x 4 up to 64, 2 x 8 up to 128), bands handed from CU to
+    CU through memory.  Odd widths (cache lines of the handed-over row straddle the groups), every
+    filter type, RGB and palette images, 200+ rows (several rounds of bands per slot) -- against the
+    oracle; one image with a filter byte > 4 fails alone (the failure flag is global)."""
+    from debigulator_amd.png_device import DevicePngBatch
+
+    rng = np.random.default_rng(n)
+    shapes = [(97, 333, 6), (501, 260, 6), (64, 200, 2), (333, 140, 3), (1030, 70, 6)]
+    pngs, want = [], []
+    for i in range(n):
+        w, h, ct = shapes[i % len(shapes)]
+        pal = rng.integers(0, 256, 768, dtype=np.uint8) if ct == 3 else None
+        png, pix = workload.make_png(500 + i, w, h, ct=ct, ftype=(5, 4, 3, 1, 2)[i % 5], noise=6, enc="dynamic", palette=pal)
+        pngs.append(png)
+        if ct == 2:  # the device batch class gives the spec-conforming RGBA image (the reference's RGB bug replay is
+            rgba = np.full((h, w, 4), 255, dtype=np.uint8)  # another kernel): the generator's pixels + alpha 255
+            rgba[:, :, :3] = np.asarray(pix).reshape(h, w, 3)
+            want.append((1, rgba.reshape(-1)))
+        else:
+            want.append(oracle.decode_png(png))
+    b = DevicePngBatch(pngs, device=gpu_device)
+    b.launch()
+    res, ires = b.results()
+    assert (res["good"] == 1).all() and (ires["good"] == 1).all()
+    for i in range(n):
+        g, px = want[i]
+        assert g == 1
+        assert np.array_equal(b.rgba(i).reshape(-1), np.asarray(px).reshape(-1)), i
+    # a filter byte > 4 in the middle of image 1 (second band's wavefront finds it): that image fails, the others do not
+    st = b.inflate
+    off = int(st.streams_host[1]["out_off"])
+    w1, h1, _ = shapes[1]
+    row = 100
+    b.launch_inflate_only()
+    st.d_out[off + row * (4 * w1 + 1)] = 9
+    b.launch_defilter_only()
+    _, ires = b.results()
+    assert ires[1]["good"] == 0 and int(ires[1]["bad_row"]) == row
+    assert all(ires[i]["good"] == 1 for i in range(n) if i != 1)
+
+
 def test_cfg5_shape_gzip_members(gpu_device, oracle):
     """gzip members of 1 MiB (text-like, dynamic Huffman, EOB >= 8 bits so the tail rule never
     truncates): header located on the host, payloads inflated in one launch."""
