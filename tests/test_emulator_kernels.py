@@ -771,3 +771,29 @@ def test_chunked_path_random_streams_agree_with_oracle(emu, oracle, seed, chunk)
         assert out == eo, i
     for (io, oo), cap in zip(offs, caps):
         assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
+
+
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT])
+def test_randomised_dynamic_headers(emu, oracle, nw):
+    """tests/header_fuzz.py: random prefix codes and a randomised run-length coding of the code-length
+    sequence (16 at the start, runs across the alphabets, runs that reach behind the last length,
+    damaged headers): the 64-positions-at-a-time header decoder against the oracle's serial one
+    (src/inflate.c:1416-1520)."""
+    import header_fuzz as hf
+    cs = hf.cases(120 if nw != 4 else 60)
+    raws = [c[0] + bytes(8) for c in cs]  # bytes behind the last block: the reference's tail gate stays out of it
+    caps = [max(2048, len(r) + 1) for r in raws]
+    outs, _, _ = eb.emu_inflate(emu, raws, caps, nw=nw, in_misalign=1)
+    n_plain = 0
+    n_damaged = 0
+    for (_, plain), raw, cap, (good, final, out, r) in zip(cs, raws, caps, outs):
+        eg, ef, eo, st = oracle.inflate(raw, cap, want_stats=True)
+        if st.ub_flags & (0x10 | 0x02):
+            continue  # over-subscribed codes / repeat at position 0: the reference has no defined answer
+        assert (good, final, out) == (eg, ef, eo[:ef or 0])
+        if plain is not None and eg == 1:  # (a valid stream may still fail the reference: a code length >= its alphabet size, Q6)
+            assert out == plain
+            n_plain += 1
+        elif plain is None:
+            n_damaged += 1
+    assert n_plain > len(cs) // 2 and n_damaged > len(cs) // 8

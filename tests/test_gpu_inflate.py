@@ -597,3 +597,16 @@ def test_golden_corpora_reference_made(gpu_device):
             want = k.get("out_sha256") or hashlib.sha256(bytes.fromhex(k["out_hex"])).hexdigest()
             assert hashlib.sha256(got).hexdigest() == want, (width, i)
             assert not host[off + caps[i]:off + caps[i] + 32].any()
+
+
+def test_randomised_dynamic_headers(oracle, gpu_device):
+    """tests/header_fuzz.py: random prefix codes for the three alphabets and a randomised run-length
+    coding of the code-length sequence (runs across the alphabets, runs that reach behind the last
+    length, damaged headers) -- the header decoder that looks 64 bit positions up at a time
+    (decode_code_lengths, inflate_kernel.inc) against the oracle's serial loop (src/inflate.c:1416-1520),
+    every width."""
+    import header_fuzz as hf
+    cs = hf.cases(600)
+    raws = [c[0] + bytes(8) for c in cs]
+    caps = [max(2048, len(r) + 1) for r in raws]
+    _check(oracle, gpu_device, raws, caps)

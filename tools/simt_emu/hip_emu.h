@@ -213,6 +213,7 @@ static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 static inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
 static inline int __clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
+static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 static inline unsigned __brev(unsigned v)
 {
     unsigned r = 0;
