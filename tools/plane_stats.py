@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: in the chunk-parallel path every task k >= 1 is replayed into TWO planes (synthetic
-histories A and B); a byte that differs between the planes derives from the 32 KiB window in front of
+"""Diagnostic: in the chunk-parallel path every task k >= 1 is replayed in 16-bit elements {a, b}
+(synthetic histories A and B); an element with a != b derives from the 32 KiB window in front of
 the task.  How far into a task's output do such bytes reach?  (If they die out, the second plane is
 dead weight from there on.)   python tools/plane_stats.py KIND COUNT MBYTES_EACH"""
 import os, sys
@@ -56,9 +56,9 @@ for i in range(n):
             continue
         tot = int(s["out_total"])
         blk = planes_off + int(c["base"]) + int(t["plane_rel"])
-        pa = blk + 2 * H
-        pb = pa + al(H + tot)
-        A, B = ws[pa:pa + tot], ws[pb:pb + tot]
+        pw = blk + H + 2 * H  # the true window, then the wide plane: H synthetic elements, then the task's
+        el = ws[pw:pw + 2 * tot].view("<u2")
+        A, B = el & 255, el >> 8
         d = np.flatnonzero(A != B)
         tot_bytes += tot
         tot_diff += d.size
