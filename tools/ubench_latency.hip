@@ -89,6 +89,42 @@ template <int CH> __global__ void k_decode(const uint16_t *tab, const uint32_t *
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// the same recurrence with the second table look-up replaced by arithmetic on the bits (a fixed-Huffman
+// distance code: 5 bits, reversed; extra bits from the symbol)
+template <int CH> __global__ void k_decode_fx(const uint16_t *tab, const uint32_t *win, uint32_t *out, uint64_t *cyc)
+{
+    __shared__ uint16_t T[2048];
+    __shared__ uint32_t W[1104];
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) T[i] = tab[i];
+    for (int i = threadIdx.x; i < 1104; i += blockDim.x) W[i] = win[i];
+    __syncthreads();
+    uint32_t lp[CH];
+    for (int c = 0; c < CH; c++) lp[c] = ((threadIdx.x & 63u) * 544u + c * 1000u) % 30000u;
+    uint64_t t0 = now();
+    for (int i = 0; i < N_IT; i++) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            uint32_t w = lp[c] >> 5;
+            uint32_t d0 = W[w], d1 = W[w + 1], d2 = W[w + 2];
+            uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, lp[c]);
+            uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, lp[c]);
+            uint32_t e = T[lo & 511u];
+            uint32_t n1 = (e & 15u) + ((e >> 4) & 7u);
+            uint32_t b2 = __builtin_amdgcn_alignbit(hi, lo, n1);
+            uint32_t D = __builtin_bitreverse32(b2) >> 27;
+            uint32_t ex = (D >> 1) > 1u ? (D >> 1) - 1u : 0u;
+            uint32_t y = (e & 128u) ? 5u + ex : 0u;
+            lp[c] += n1 + y + 1u;
+            lp[c] = lp[c] > 30000u ? lp[c] - 30000u : lp[c];
+        }
+    }
+    uint64_t t1 = now();
+    uint32_t s = 0;
+    for (int c = 0; c < CH; c++) s += lp[c];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
 template <class F> static void run(const char *name, F launch, int blocks, uint64_t *d_cyc, double per)
 {
     launch();
@@ -124,6 +160,7 @@ int main()
         run("LDS u16 chase, 2 chains", [&] { k_lds<2><<<blocks, 64>>>(d_tab, d_out, d_cyc); }, blocks, d_cyc, 2);
         run("LDS u16 chase, 4 chains", [&] { k_lds<4><<<blocks, 64>>>(d_tab, d_out, d_cyc); }, blocks, d_cyc, 4);
         run("decode recurrence, 1 chain", [&] { k_decode<1><<<blocks, 64>>>(d_tab, d_win, d_out, d_cyc); }, blocks, d_cyc, 1);
+        run("decode, distance by arithmetic, 1 chain", [&] { k_decode_fx<1><<<blocks, 64>>>(d_tab, d_win, d_out, d_cyc); }, blocks, d_cyc, 1);
         run("decode recurrence, 2 chains", [&] { k_decode<2><<<blocks, 64>>>(d_tab, d_win, d_out, d_cyc); }, blocks, d_cyc, 2);
         run("decode recurrence, 4 chains", [&] { k_decode<4><<<blocks, 64>>>(d_tab, d_win, d_out, d_cyc); }, blocks, d_cyc, 4);
     }
