@@ -199,7 +199,7 @@ def test_compat_archive_has_the_literal_inflate_symbol(native_lib):
 def test_dispatch_plan_rules():
     """debigulator_amd.batch.plan_batch mirrors csrc/host/debig_ctx.h (debig_pick_waves /
     debig_plan_batch): few streams that are large on average, or thousands with a very large one
-    among them, go through chunk tasks; a skewed batch of 513..1024 is launched longest first."""
+    among them, go through chunk tasks; a skewed batch of 513..1024 is launched 4-wide, most bytes touched first."""
     import numpy as np
 
     from debigulator_amd import _native as N
@@ -220,3 +220,10 @@ def test_dispatch_plan_rules():
     assert plan_batch(streams([65536] * 8192)) == (None, 0)
     order, waves = plan_batch(streams([1000] * 600 + [500000] * 200))
     assert waves == 4 and list(order[:3]) == [600, 601, 602]
+    # ... and the order goes by the bytes a stream touches (in_len + out_cap): a small input that
+    # decodes to megabytes starts with the long ones
+    s = streams([1000] * 600 + [500000] * 200)
+    s["out_cap"] = s["in_len"] * 3
+    s["out_cap"][5] = 4 << 20
+    order, waves = plan_batch(s)
+    assert waves == 4 and list(order[:3]) == [5, 600, 601]
