@@ -35,6 +35,7 @@ class DebigPngResult(C.Structure):
 
 
 WAVES_SPLIT = 0x10  # include/debig_hip.h: DEBIG_WAVES_SPLIT
+WAVES_SPLIT_QUEUED = 0x11  # DEBIG_WAVES_SPLIT_QUEUED: persistent workgroups + work queue
 WAVES_CHUNKED = 0x20  # include/debig_hip.h: DEBIG_WAVES_CHUNKED
 
 _lib = None
@@ -67,6 +68,8 @@ def lib():
     L.debig_hip_inflate_plan_ws.argtypes = [vp, u32, vp, u64, vp]
     L.debig_hip_inflate_planned_ws.restype = C.c_int
     L.debig_hip_inflate_planned_ws.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp]
+    L.debig_hip_inflate_planned_ws_ex.restype = C.c_int
+    L.debig_hip_inflate_planned_ws_ex.argtypes = [vp, vp, vp, vp, u32, u32, vp, u64, vp]
     L.debig_hip_init.restype = C.c_int
     L.debig_hip_init.argtypes = [vp]
     L.debig_hip_inflate_batch_ws.restype = C.c_int

@@ -129,7 +129,7 @@ class DeviceBatch:
         """Asynchronous: one kernel launch on `stream` (default: torch's current stream).
         waves_per_stream: 1 (one wavefront per stream), 2 / 4 / 8 (one stream per workgroup of
         that many wavefronts, for few large streams), _native.WAVES_SPLIT (scan + LZ77 kernel pair,
-        the throughput path), 0 = library's choice from the batch size."""
+        the throughput path; WAVES_SPLIT_QUEUED: behind persistent workgroups and a work queue), 0 = library's choice from the batch size."""
         torch = self.torch
         if stream is None:
             stream = torch.cuda.current_stream(self.device)
@@ -140,8 +140,8 @@ class DeviceBatch:
         if waves_per_stream == N.WAVES_CHUNKED:
             return self._launch_chunked(stream)
         ws_ptr, ws_bytes = None, 0
-        if waves_per_stream == N.WAVES_SPLIT or (waves_per_stream == 0 and self.n > 1024 and
-                                                 not os.environ.get("DEBIG_WAVES_PER_STREAM")):
+        if waves_per_stream in (N.WAVES_SPLIT, N.WAVES_SPLIT_QUEUED) or (waves_per_stream == 0 and self.n > 1024 and
+                                                                         not os.environ.get("DEBIG_WAVES_PER_STREAM")):
             if self.d_ws is None:  # caller-owned workspace: nothing is allocated inside the call
                 total_in = int(self.streams_host["in_len"].sum())
                 nbytes = int(self.lib.debig_hip_inflate_workspace_bytes(total_in, self.n))
@@ -154,10 +154,11 @@ class DeviceBatch:
                     N.check(self.lib.debig_hip_inflate_plan_ws(self.d_streams.data_ptr(), self.n, ws_ptr, ws_bytes,
                                                                C.c_void_p(stream.cuda_stream)), "debig_hip_inflate_plan_ws")
                     self._planned = True
-                N.check(self.lib.debig_hip_inflate_planned_ws(self.d_in.data_ptr(), self.d_out.data_ptr(),
-                                                              self.d_streams.data_ptr(), self.d_results.data_ptr(), self.n,
-                                                              ws_ptr, ws_bytes, C.c_void_p(stream.cuda_stream)),
-                        "debig_hip_inflate_planned_ws")
+                N.check(self.lib.debig_hip_inflate_planned_ws_ex(self.d_in.data_ptr(), self.d_out.data_ptr(),
+                                                                 self.d_streams.data_ptr(), self.d_results.data_ptr(), self.n,
+                                                                 waves_per_stream or N.WAVES_SPLIT,
+                                                                 ws_ptr, ws_bytes, C.c_void_p(stream.cuda_stream)),
+                        "debig_hip_inflate_planned_ws_ex")
                 return
         rc = self.lib.debig_hip_inflate_batch_ws(self.d_in.data_ptr(), self.d_out.data_ptr(),
                                                  self.d_streams.data_ptr(), self.d_results.data_ptr(),

@@ -186,11 +186,29 @@ static DefaultWs *default_workspace(hipStream_t s)
 // pair handed back.  Returns 0, a hipError_t, or -1 when the workspace is too small to try.
 // what = 1: carve the workspace only (debig_split_plan_kernel), 2: scan + lz + hand-back over a
 // workspace already carved for exactly these descriptors, 3: both (one call does everything)
+// workgroups of debig_scanlz_queue_kernel the current device holds at once (per device, asked once)
+static uint32_t scanlz_resident_workgroups()
+{
+    static uint32_t cap[64];
+    const char *e = getenv("DEBIG_SPLIT_WORKGROUPS"); /* tests and experiments: read at every call */
+    const uint32_t forced = e && *e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
+    if (forced) return forced;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 4096u;
+    if (cap[dev] == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, debig_scanlz_queue_kernel, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cap[dev] = (uint32_t)per_cu * (uint32_t)cus;
+    }
+    return cap[dev];
+}
+
 static int launch_split_group(hipStream_t s, const void *d_in, void *d_out, const debig_stream *d_streams,
                               debig_result *d_results, uint32_t n, const FixedTabs *tabs, void *ws, uint64_t ws_bytes,
-                              int what = 3)
+                              int what = 3, int queued = 0)
 {
-    const uint64_t slots_bytes = align_up((uint64_t)n * sizeof(debig_ws_slot), 256);
+    const uint64_t slots_bytes = align_up((uint64_t)n * sizeof(debig_ws_slot) + 4u * SPLIT_QUEUE_WORDS, 256); /* + the work queue */
     if (ws_bytes < slots_bytes + (uint64_t)n * 1024u) return -1;
     const uint64_t rest = ws_bytes - slots_bytes;
     const uint64_t total_recs = rest / 16u / sizeof(debig_ws_rec);
@@ -206,8 +224,13 @@ static int launch_split_group(hipStream_t s, const void *d_in, void *d_out, cons
 #define DEBIG_SPLIT_FUSED 1
 #endif
 #if DEBIG_SPLIT_FUSED
-    hipLaunchKernelGGL(debig_scanlz_kernel, dim3(n), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, n,
-                       tabs->scan, slots, recs, rows, d_results);
+    const uint32_t cap = queued ? scanlz_resident_workgroups() : 0u;
+    if (queued && n > cap) /* persistent workgroups: as many as the device holds at once, streams from a queue */
+        hipLaunchKernelGGL(debig_scanlz_queue_kernel, dim3(cap), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out,
+                           d_streams, n, tabs->scan, slots, recs, rows, d_results);
+    else
+        hipLaunchKernelGGL(debig_scanlz_kernel, dim3(n), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, n,
+                           tabs->scan, slots, recs, rows, d_results);
 #else
     hipLaunchKernelGGL(debig_scan_kernel, dim3(n), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, n,
                        tabs->scan, slots, recs, rows, d_results);
@@ -220,11 +243,11 @@ static int launch_split_group(hipStream_t s, const void *d_in, void *d_out, cons
 }
 
 static int launch_split(hipStream_t s, const void *d_in, void *d_out, const debig_stream *d_streams,
-                        debig_result *d_results, uint32_t n, const FixedTabs *tabs, void *ws, uint64_t ws_bytes)
+                        debig_result *d_results, uint32_t n, const FixedTabs *tabs, void *ws, uint64_t ws_bytes, int queued = 0)
 {
     for (uint32_t first = 0; first < n; first += SPLIT_GROUP) {
         const uint32_t cnt = n - first < SPLIT_GROUP ? n - first : SPLIT_GROUP;
-        int rc = launch_split_group(s, d_in, d_out, d_streams + first, d_results + first, cnt, tabs, ws, ws_bytes);
+        int rc = launch_split_group(s, d_in, d_out, d_streams + first, d_results + first, cnt, tabs, ws, ws_bytes, 3, queued);
         if (rc) return rc;
     }
     return 0;
@@ -337,7 +360,8 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
     if (waves_per_stream == 0) waves_per_stream = auto_waves_per_stream(n);
     const int mixed = waves_per_stream == DEBIG_WAVES_LARGE4_SMALL1 || waves_per_stream == DEBIG_WAVES_LARGE4_SMALL2;
     if (!mixed && waves_per_stream != 1 && waves_per_stream != 2 && waves_per_stream != 4 && waves_per_stream != 8 &&
-        waves_per_stream != DEBIG_WAVES_SPLIT && waves_per_stream != DEBIG_WAVES_CHUNKED)
+        waves_per_stream != DEBIG_WAVES_SPLIT && waves_per_stream != DEBIG_WAVES_SPLIT_QUEUED &&
+        waves_per_stream != DEBIG_WAVES_CHUNKED)
         return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)hip_stream;
     const FixedTabs *ft = fixed_tables(s);
@@ -357,7 +381,7 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
         d_workspace = nullptr;
         waves_per_stream = n <= 256u ? 8u : n <= 512u ? 4u : n <= 1024u ? 2u : 1u; /* no usable workspace */
     }
-    if (waves_per_stream == DEBIG_WAVES_SPLIT) {
+    if (waves_per_stream == DEBIG_WAVES_SPLIT || waves_per_stream == DEBIG_WAVES_SPLIT_QUEUED) {
         DefaultWs *shared = nullptr;
         if (!d_workspace) {
             shared = default_workspace(s);
@@ -366,7 +390,8 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
         int rc = -1;
         if (d_workspace) {
             SharedWsUse hold(shared, s);
-            rc = launch_split(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes);
+            rc = launch_split(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes,
+                              waves_per_stream == DEBIG_WAVES_SPLIT_QUEUED);
         }
         if (rc >= 0) return rc;
         waves_per_stream = 1; /* no usable workspace: the one-kernel path */
@@ -402,17 +427,27 @@ int debig_hip_inflate_plan_ws(const debig_stream *d_streams, uint32_t n, void *d
     return rc < 0 ? (int)hipErrorInvalidValue : rc;
 }
 
-int debig_hip_inflate_planned_ws(const void *d_in, void *d_out, const debig_stream *d_streams, debig_result *d_results,
-                                 uint32_t n, void *d_workspace, uint64_t workspace_bytes, void *hip_stream)
+int debig_hip_inflate_planned_ws_ex(const void *d_in, void *d_out, const debig_stream *d_streams, debig_result *d_results,
+                                    uint32_t n, uint32_t waves_per_stream, void *d_workspace, uint64_t workspace_bytes,
+                                    void *hip_stream)
 {
     if (n == 0) return 0;
     if (n > SPLIT_GROUP || !d_workspace) return (int)hipErrorInvalidValue;
+    if (waves_per_stream != DEBIG_WAVES_SPLIT && waves_per_stream != DEBIG_WAVES_SPLIT_QUEUED) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)hip_stream;
     DeviceGuard launch_guard(launch_device(s));
     const FixedTabs *ft = fixed_tables(s);
     if (!ft) return (int)hipErrorOutOfMemory;
-    int rc = launch_split_group(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes, 2);
+    int rc = launch_split_group(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes, 2,
+                                waves_per_stream == DEBIG_WAVES_SPLIT_QUEUED);
     return rc < 0 ? (int)hipErrorInvalidValue : rc;
+}
+
+int debig_hip_inflate_planned_ws(const void *d_in, void *d_out, const debig_stream *d_streams, debig_result *d_results,
+                                 uint32_t n, void *d_workspace, uint64_t workspace_bytes, void *hip_stream)
+{
+    return debig_hip_inflate_planned_ws_ex(d_in, d_out, d_streams, d_results, n, DEBIG_WAVES_SPLIT, d_workspace, workspace_bytes,
+                                           hip_stream);
 }
 
 int debig_hip_init(void *hip_stream)

@@ -123,6 +123,16 @@ int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d
  *              one of DEBIG_WORKSPACE_MB MiB, default 1024); a stream that does not fit its share
  *              is decoded by the one-kernel path in the same call. */
 #define DEBIG_WAVES_SPLIT 0x10u
+/*   DEBIG_WAVES_SPLIT_QUEUED
+ *              DEBIG_WAVES_SPLIT for a batch whose ORDER mixes cheap and expensive streams (stored and
+ *              Huffman streams alternating, thumbnails beside full images): workgroups that stay on
+ *              the device and take streams from a queue instead of one workgroup per stream.  The
+ *              hardware deals workgroups to its shader engines by index, whatever they cost, so with
+ *              DEBIG_WAVES_SPLIT an alternating order can leave half the chip idle (4096 Huffman
+ *              streams alternating with 4096 tiny ones: 1.67 ms, queued 0.98 ms, sorted by kind 0.89 ms).
+ *              Never picked by 0: a batch sorted or grouped by kind / size is 2-4 % faster with
+ *              DEBIG_WAVES_SPLIT.  DEBIG_SPLIT_WORKGROUPS overrides the number of resident workgroups. */
+#define DEBIG_WAVES_SPLIT_QUEUED 0x11u
 /*   DEBIG_WAVES_CHUNKED
  *              a FEW LARGE streams (hundreds of big PNG images): every stream is cut at DEFLATE
  *              block boundaries into chunk tasks of 32..256 KiB of input, found by looking for
@@ -180,6 +190,12 @@ int debig_hip_inflate_plan_ws(const debig_stream *d_streams, uint32_t n, void *d
                               void *hip_stream);
 int debig_hip_inflate_planned_ws(const void *d_in, void *d_out, const debig_stream *d_streams, debig_result *d_results,
                                  uint32_t n, void *d_workspace, uint64_t workspace_bytes, void *hip_stream);
+/* the same with the dispatch named: DEBIG_WAVES_SPLIT (what debig_hip_inflate_planned_ws runs) or
+ * DEBIG_WAVES_SPLIT_QUEUED (persistent workgroups over a work queue: batches whose order mixes cheap and
+ * expensive streams); anything else: hipErrorInvalidValue */
+int debig_hip_inflate_planned_ws_ex(const void *d_in, void *d_out, const debig_stream *d_streams,
+                                    debig_result *d_results, uint32_t n, uint32_t waves_per_stream,
+                                    void *d_workspace, uint64_t workspace_bytes, void *hip_stream);
 
 /* One image for the de-filter kernel: the inflated scanline stream (filter byte
  * + w*bpp bytes per row) -> 4-channel RGBA. */

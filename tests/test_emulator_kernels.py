@@ -26,10 +26,10 @@ def emu():
 
 
 # wavefronts per stream: 1 = debig_inflate_kernel, 2 / 4 = debig_inflate_mw_kernel<NW>
-@pytest.mark.parametrize("nw", [1, 2, 4, eb.SPLIT])
+@pytest.mark.parametrize("nw", [1, 2, 4, eb.SPLIT, eb.SPLIT_QUEUED])
 def test_known_answers_and_corpus(emu, nw):
     items = json.load(open(os.path.join(GOLD, "kat.json")))
-    items += json.load(open(os.path.join(GOLD, "corpus_zlib.json")))[:80 if nw in (1, eb.SPLIT) else 40]
+    items += json.load(open(os.path.join(GOLD, "corpus_zlib.json")))[:80 if nw in (1, eb.SPLIT, eb.SPLIT_QUEUED) else 40]
     raws = [bytes.fromhex(k["raw_hex"]) for k in items]
     caps = [k["recipient_size"] for k in items]
     outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, in_misalign=3, out_misalign=5)
@@ -44,10 +44,10 @@ def test_known_answers_and_corpus(emu, nw):
         assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
 
 
-@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.SPLIT_QUEUED])
 def test_corrupt_corpus_reference_made(emu, nw):
     """tests/golden/corpus_corrupt.json: damaged streams with the REFERENCE's own answers (build B)"""
-    items = json.load(open(os.path.join(GOLD, "corpus_corrupt.json")))[:: 1 if nw in (1, eb.SPLIT) else 3]
+    items = json.load(open(os.path.join(GOLD, "corpus_corrupt.json")))[:: 1 if nw in (1, eb.SPLIT, eb.SPLIT_QUEUED) else 3]
     raws = [bytes.fromhex(k["raw_hex"]) for k in items]
     caps = [k["recipient_size"] for k in items]
     outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, out_misalign=1)

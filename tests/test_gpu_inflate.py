@@ -51,7 +51,8 @@ def _payload(rng, n, kind):
 # mixed modes (large streams 4-wide beside small ones 1- / 2-wide, include/debig_hip.h)
 # 0x10 = DEBIG_WAVES_SPLIT: the scan + LZ77 kernel pair (what the library picks for n > 1024)
 # 0x20 = DEBIG_WAVES_CHUNKED: large streams cut into chunk tasks at block headers
-WIDTHS = (1, 2, 4, 8, 0x41, 0x42, 0x10, 0x20)
+# 0x11 = DEBIG_WAVES_SPLIT_QUEUED: the pair behind persistent workgroups and a work queue
+WIDTHS = (1, 2, 4, 8, 0x41, 0x42, 0x10, 0x11, 0x20)
 
 
 def _check(oracle, gpu_device, raws, caps, widths=WIDTHS, **kw):
@@ -610,3 +611,28 @@ def test_randomised_dynamic_headers(oracle, gpu_device):
     raws = [c[0] + bytes(8) for c in cs]
     caps = [max(2048, len(r) + 1) for r in raws]
     _check(oracle, gpu_device, raws, caps)
+
+
+def test_queued_dispatch_few_workgroups_many_launches(oracle, gpu_device, monkeypatch):
+    """DEBIG_WAVES_SPLIT_QUEUED with far fewer resident workgroups than streams (DEBIG_SPLIT_WORKGROUPS = 5
+    for 300 streams of very different cost, alternating) and the same plan executed several times: the
+    queue counter is never reset, every launch must hand every stream out exactly once."""
+    monkeypatch.setenv("DEBIG_SPLIT_WORKGROUPS", "5")
+    rng = random.Random(77)
+    raws, plains = [], []
+    for i in range(300):
+        p = _payload(rng, 200 if i % 2 else rng.randint(20000, 60000), i % 5)
+        plains.append(p)
+        raws.append(_zlib_raw(p, level=rng.choice([0, 1, 6, 9])) + bytes(8))
+    caps = [max(len(p) + 16, len(r) + 1) for p, r in zip(plains, raws)]
+    b = DeviceBatch.from_streams(raws, caps, device=gpu_device)
+    for _ in range(4):
+        b.d_out.zero_()
+        b.d_results.zero_()
+        b.launch(waves_per_stream=0x11)
+        res = b.results()
+        assert (res["good"] == 1).all()
+        for i in (0, 1, 2, 150, 298, 299):
+            assert b.output(i, res) == plains[i]
+        want = [oracle.inflate(r, c)[:2] for r, c in zip(raws[:40], caps[:40])]
+        assert [(int(res[i]["good"]), int(res[i]["final_size"])) for i in range(40)] == want

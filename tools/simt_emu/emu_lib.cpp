@@ -80,7 +80,7 @@ extern "C" int emu_inflate_split_batch(const void *in, void *out, const debig_st
         fts = (uint32_t *)calloc(1, sizeof(decltype(ScanLds::t)));
         EMU_LAUNCH(debig_scan_fixed_tables_kernel, 1, 64, fts);
     }
-    const uint64_t slots_bytes = ((uint64_t)n * sizeof(debig_ws_slot) + 255) / 256 * 256;
+    const uint64_t slots_bytes = ((uint64_t)n * sizeof(debig_ws_slot) + 4u * SPLIT_QUEUE_WORDS + 255) / 256 * 256;
     if (ws_bytes < slots_bytes + (uint64_t)n * 1024u) return -1;
     uint8_t *ws = (uint8_t *)malloc(ws_bytes);
     memset(ws, 0xEE, ws_bytes); /* poison: nothing may be read before it is written */
@@ -97,7 +97,17 @@ extern "C" int emu_inflate_split_batch(const void *in, void *out, const debig_st
         EMU_LAUNCH(debig_lz_kernel, n, 64, (uint8_t *)out, streams, results, n, (const debig_ws_slot *)slots,
                    (const debig_ws_rec *)recs, (const uint32_t *)rows);
     } else {
-        EMU_LAUNCH(debig_scanlz_kernel, n, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
+        if (getenv("DEBIG_EMU_SPLIT_QUEUED")) {
+            // DEBIG_WAVES_SPLIT_QUEUED: fewer workgroups than streams, and twice (the queue counter carries on)
+            const uint32_t grid = n > 3u ? 3u : n;
+            const uint64_t *q = reinterpret_cast<const uint64_t *>(split_queue(slots, n));
+            EMU_LAUNCH(debig_scanlz_queue_kernel, grid, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
+            if (*q != (uint64_t)n) return -2; /* a launch adds exactly n to the queue counter */
+            EMU_LAUNCH(debig_scanlz_queue_kernel, grid, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
+            if (*q != 2u * (uint64_t)n) return -2;
+        } else {
+            EMU_LAUNCH(debig_scanlz_kernel, n, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
+        }
     }
     uint32_t retried = 0;
     for (uint32_t i = 0; i < n; i++) retried += results[i].status == DEBIG_E_RETRY;
