@@ -68,6 +68,8 @@ def lib():
     L.debig_hip_inflate_plan_ws.argtypes = [vp, u32, vp, u64, vp]
     L.debig_hip_inflate_planned_ws.restype = C.c_int
     L.debig_hip_inflate_planned_ws.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp]
+    L.debig_hip_mem_free.restype = C.c_uint64
+    L.debig_hip_mem_free.argtypes = []
     L.debig_hip_inflate_planned_ws_ex.restype = C.c_int
     L.debig_hip_inflate_planned_ws_ex.argtypes = [vp, vp, vp, vp, u32, u32, vp, u64, vp]
     L.debig_hip_init.restype = C.c_int

@@ -172,20 +172,32 @@ class DeviceBatch:
         DEBIG_CHUNKED_WS_MB (default 40960) MiB; one workspace, reused group after group."""
         torch = self.torch
         if self.chunk_groups is None:
-            cap = int(os.environ.get("DEBIG_CHUNKED_WS_MB", "40960")) << 20
+            # few, large groups (every group pays the window kernel's serial walk and a dozen launch tails:
+            # profiles/r03_chunk_workspace_groups.txt): a group may take what the device has free, less an
+            # eighth (at least 40 GiB asked for); DEBIG_CHUNKED_WS_MB overrides.  Same rule as csrc/host/debig_ctx.c
+            if os.environ.get("DEBIG_CHUNKED_WS_MB"):
+                cap = int(os.environ["DEBIG_CHUNKED_WS_MB"]) << 20
+            else:
+                free = int(torch.cuda.mem_get_info(self.device)[0])
+                cap = max(40960 << 20, free - free // 8)
             need = lambda a, b, c: int(self.lib.debig_hip_inflate_chunked_workspace_bytes(int(a), int(b), int(c)))
-            groups, first, tin, tout, biggest = [], 0, 0, 0, 0
             ds = self.dev_streams_host
-            for i in range(self.n):
-                a, b = int(ds[i]["in_len"]), int(ds[i]["out_cap"])
-                if i > first and need(tin + a, tout + b, i - first + 1) > cap:
-                    groups.append((first, i - first))
-                    biggest = max(biggest, need(tin, tout, i - first))
-                    first, tin, tout = i, 0, 0
-                tin += a
-                tout += b
-            groups.append((first, self.n - first))
-            biggest = max(biggest, need(tin, tout, self.n - first))
+
+            def carve(per_group):
+                groups, first, tin, tout, biggest = [], 0, 0, 0, 0
+                for i in range(self.n):
+                    a, b = int(ds[i]["in_len"]), int(ds[i]["out_cap"])
+                    if i > first and (need(tin + a, tout + b, i - first + 1) > cap or i - first >= per_group):
+                        groups.append((first, i - first))
+                        biggest = max(biggest, need(tin, tout, i - first))
+                        first, tin, tout = i, 0, 0
+                    tin += a
+                    tout += b
+                groups.append((first, self.n - first))
+                return groups, max(biggest, need(tin, tout, self.n - first))
+
+            groups, biggest = carve(self.n)
+            groups, biggest = carve(-(-self.n // len(groups)))  # evened out: as many streams in each as the fullest needs
             self.chunk_groups = groups
             try:
                 self.d_ws_chunked = torch.empty(biggest, dtype=torch.uint8, device=self.device)

@@ -591,6 +591,12 @@ int debig_hip_get_device(void)
     int dev = -1;
     return hipGetDevice(&dev) == hipSuccess ? dev : -1;
 }
+uint64_t debig_hip_mem_free(void)
+{
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
+    return (uint64_t)fr;
+}
 void *debig_hip_malloc(uint64_t bytes)
 {
     void *p = nullptr;

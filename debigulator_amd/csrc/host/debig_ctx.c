@@ -294,10 +294,35 @@ int debig_launch_inflate_planned(debig_ctx *c, const void *d_in_arena, const deb
         /* fall through to the cleanup */
     } else if (w == DEBIG_WAVES_CHUNKED) {
         /* chunk tasks need about 5 bytes of workspace per decoded byte: the batch goes through in
-         * groups of streams that fit DEBIG_CHUNKED_WS_MB (default 40960) MiB, launched back to back */
+         * groups of streams, launched back to back.  FEW, LARGE groups: every group pays the serial
+         * walk of the window kernel and a dozen launch tails (config 4, 32 images: two groups 75.7 ms,
+         * one group 63.9 ms; profiles/r03_chunk_workspace_groups.txt), so a group may take what the
+         * device has free (less an eighth, at least 40 GiB asked for), DEBIG_CHUNKED_WS_MB overrides;
+         * the groups are evened out (as many streams in each as the fullest needs) */
         uint64_t cap = 40960ull << 20;
         const char *e = getenv("DEBIG_CHUNKED_WS_MB");
         if (e && *e) cap = strtoull(e, NULL, 0) << 20;
+        else {
+            const uint64_t fr = debig_hip_mem_free() + c->ws.cap; /* what the context's workspace holds is ours to reuse */
+            if (fr - fr / 8u > cap) cap = fr - fr / 8u;
+        }
+        /* how many streams per group when the groups are even */
+        uint32_t per_group = n;
+        {
+            uint32_t groups = 0, first = 0;
+            while (first < n) {
+                uint64_t tin = 0, tout = 0;
+                uint32_t cnt = 0;
+                while (first + cnt < n) {
+                    const uint64_t a = up[first + cnt].in_len, b = up[first + cnt].out_cap;
+                    if (cnt && debig_hip_inflate_chunked_workspace_bytes(tin + a, tout + b, cnt + 1u) > cap) break;
+                    tin += a; tout += b; cnt++;
+                }
+                first += cnt;
+                groups++;
+            }
+            per_group = (n + groups - 1u) / groups;
+        }
         /* pass 0 sizes the largest group (one reservation: growing the buffer between launches would
          * wait for the device), pass 1 launches */
         uint64_t biggest = 0;
@@ -310,7 +335,7 @@ int debig_launch_inflate_planned(debig_ctx *c, const void *d_in_arena, const deb
                 while (first + cnt < n) {
                     const uint64_t a = up[first + cnt].in_len, b = up[first + cnt].out_cap;
                     const uint64_t nd = debig_hip_inflate_chunked_workspace_bytes(tin + a, tout + b, cnt + 1u);
-                    if (cnt && nd > cap) break;
+                    if (cnt && (nd > cap || cnt >= per_group)) break;
                     tin += a; tout += b; need = nd; cnt++;
                 }
                 if (need > cap) need = cap; /* one stream larger than the cap: the chunk path hands it back */

@@ -258,6 +258,7 @@ int debig_hip_gather(const void *d_src_arena, void *d_dst_arena, const debig_cop
 int debig_hip_device_count(void);
 int debig_hip_set_device(int dev);
 int debig_hip_get_device(void); /* the calling thread's current device, -1 on error */
+uint64_t debig_hip_mem_free(void); /* free device memory of the current device in bytes, 0 on error */
 void *debig_hip_malloc(uint64_t bytes);
 void debig_hip_free(void *p);
 int debig_hip_memcpy_h2d(void *d, const void *h, uint64_t bytes, void *hip_stream);
