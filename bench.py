@@ -362,9 +362,10 @@ def roof(c, d, ms, what, launches):
             "avg_step_ms": ms, "decompressed_GBps": d / ms / 1e6, "launches_per_step": launches}
 
 
-SPLIT_WHAT = ("one step = debig_scan_kernel + debig_lz_kernel (+ debig_inflate_kernel for streams handed back: none "
-              "here) over a workspace carved once by debig_split_plan_kernel (debig_hip_inflate_plan_ws / _planned_ws; "
-              "more than 16384 streams: plan + scan + lz + hand-back per group of 16384), whole batch on rank 0")
+SPLIT_WHAT = ("one step = debig_scanlz_kernel (the scan and LZ77 halves fused: one wavefront per stream) + "
+              "debig_inflate_kernel for streams handed back (none here), over a workspace carved once by "
+              "debig_split_plan_kernel (debig_hip_inflate_plan_ws / _planned_ws_ex; more than 16384 streams: plan + "
+              "scanlz + hand-back per group of 16384), whole batch on rank 0")
 
 
 def main():
@@ -520,7 +521,7 @@ def main():
         else:
             rl = roof(c_bytes, d_bytes, step_ms, SPLIT_WHAT if split else
                       "one step = one debig_inflate(_mw)_kernel launch, whole batch on rank 0",
-                      (3 if len(res) <= 16384 else 4 * ((len(res) + 16383) // 16384)) if split else 1)
+                      (2 if len(res) <= 16384 else 3 * ((len(res) + 16383) // 16384)) if split else 1)
         if not cfg5 and not cfg4:
             tr, src = pmc_traffic(digest, args.streams / STREAMS_PER_KIND)
             rl["traffic"] = tr
@@ -570,7 +571,7 @@ def main():
             assert (r["good"] == 1).all()
             name = "roofline_huffman" if kind == "fixed" else "roofline_stored"
             line[name] = roof(cb, db, ms, f"{kind} streams launched alone ({len(r)} x 64 KiB), same kernels",
-                              3 if len(r) > 1024 else 1)
+                              2 if len(r) > 1024 else 1)
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
 
@@ -584,7 +585,7 @@ def main():
         dt5, ms5, jd5, jc5, res5 = timed_steps(torch, np, dist, coll_dev, b5, verify5, args.cfg5_steps, 1, c5, d5)
         if rank == 0:
             r5 = roof(c5, d5, ms5, SPLIT_WHAT + " (rank 0's shard; member payloads, CRC-32 checked outside the timed region)",
-                      (3 if len(res5) <= 16384 else 4 * ((len(res5) + 16383) // 16384)) if len(res5) > 1024 else 1)
+                      (2 if len(res5) <= 16384 else 3 * ((len(res5) + 16383) // 16384)) if len(res5) > 1024 else 1)
             line["cfg5_strong"] = {
                 "value": jd5 * args.cfg5_steps / dt5 / 1e9,
                 "unit": "GB/s",
