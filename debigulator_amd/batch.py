@@ -169,7 +169,7 @@ class DeviceBatch:
     def _launch_chunked(self, stream):
         """The chunk-parallel path for few large streams: the batch goes through in groups of
         streams whose workspace need (debig_hip_inflate_chunked_workspace_bytes) fits
-        DEBIG_CHUNKED_WS_MB (default 40960) MiB; one workspace, reused group after group."""
+        the free device memory less an eighth (DEBIG_CHUNKED_WS_MB overrides); one workspace, reused group after group."""
         torch = self.torch
         if self.chunk_groups is None:
             # few, large groups (every group pays the window kernel's serial walk and a dozen launch tails:
