@@ -140,7 +140,7 @@ class DeviceBatch:
         if waves_per_stream == N.WAVES_CHUNKED:
             return self._launch_chunked(stream)
         ws_ptr, ws_bytes = None, 0
-        if waves_per_stream in (N.WAVES_SPLIT, N.WAVES_SPLIT_QUEUED) or (waves_per_stream == 0 and self.n > 1024 and
+        if waves_per_stream in (N.WAVES_SPLIT, N.WAVES_SPLIT_QUEUED, N.WAVES_STRAND) or (waves_per_stream == 0 and self.n > 1024 and
                                                                          not os.environ.get("DEBIG_WAVES_PER_STREAM")):
             if self.d_ws is None:  # caller-owned workspace: nothing is allocated inside the call
                 total_in = int(self.streams_host["in_len"].sum())

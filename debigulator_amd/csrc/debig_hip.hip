@@ -9,6 +9,7 @@
 #include "inflate_kernel.inc"
 #include "inflate_mw_kernel.inc"
 #include "inflate_split_kernel.inc"
+#include "inflate_strand_kernel.inc"
 #include "inflate_chunk_kernel.inc"
 #include "png_kernel.inc"
 #include "checksum_kernel.inc"
@@ -224,8 +225,11 @@ static int launch_split_group(hipStream_t s, const void *d_in, void *d_out, cons
 #define DEBIG_SPLIT_FUSED 1
 #endif
 #if DEBIG_SPLIT_FUSED
-    const uint32_t cap = queued ? scanlz_resident_workgroups() : 0u;
-    if (queued && n > cap) /* persistent workgroups: as many as the device holds at once, streams from a queue */
+    const uint32_t cap = queued == 1 ? scanlz_resident_workgroups() : 0u;
+    if (queued == 2) /* DEBIG_WAVES_STRAND: the long-segment scan in front of the same LZ77 half */
+        hipLaunchKernelGGL(debig_strand_kernel, dim3(n), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, n,
+                           tabs->scan, slots, recs, rows, d_results);
+    else if (queued && n > cap) /* persistent workgroups: as many as the device holds at once, streams from a queue */
         hipLaunchKernelGGL(debig_scanlz_queue_kernel, dim3(cap), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out,
                            d_streams, n, tabs->scan, slots, recs, rows, d_results);
     else
@@ -361,7 +365,7 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
     const int mixed = waves_per_stream == DEBIG_WAVES_LARGE4_SMALL1 || waves_per_stream == DEBIG_WAVES_LARGE4_SMALL2;
     if (!mixed && waves_per_stream != 1 && waves_per_stream != 2 && waves_per_stream != 4 && waves_per_stream != 8 &&
         waves_per_stream != DEBIG_WAVES_SPLIT && waves_per_stream != DEBIG_WAVES_SPLIT_QUEUED &&
-        waves_per_stream != DEBIG_WAVES_CHUNKED)
+        waves_per_stream != DEBIG_WAVES_STRAND && waves_per_stream != DEBIG_WAVES_CHUNKED)
         return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)hip_stream;
     const FixedTabs *ft = fixed_tables(s);
@@ -381,7 +385,8 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
         d_workspace = nullptr;
         waves_per_stream = n <= 256u ? 8u : n <= 512u ? 4u : n <= 1024u ? 2u : 1u; /* no usable workspace */
     }
-    if (waves_per_stream == DEBIG_WAVES_SPLIT || waves_per_stream == DEBIG_WAVES_SPLIT_QUEUED) {
+    if (waves_per_stream == DEBIG_WAVES_SPLIT || waves_per_stream == DEBIG_WAVES_SPLIT_QUEUED ||
+        waves_per_stream == DEBIG_WAVES_STRAND) {
         DefaultWs *shared = nullptr;
         if (!d_workspace) {
             shared = default_workspace(s);
@@ -391,7 +396,7 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
         if (d_workspace) {
             SharedWsUse hold(shared, s);
             rc = launch_split(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes,
-                              waves_per_stream == DEBIG_WAVES_SPLIT_QUEUED);
+                              waves_per_stream == DEBIG_WAVES_SPLIT_QUEUED ? 1 : waves_per_stream == DEBIG_WAVES_STRAND ? 2 : 0);
         }
         if (rc >= 0) return rc;
         waves_per_stream = 1; /* no usable workspace: the one-kernel path */
@@ -433,13 +438,15 @@ int debig_hip_inflate_planned_ws_ex(const void *d_in, void *d_out, const debig_s
 {
     if (n == 0) return 0;
     if (n > SPLIT_GROUP || !d_workspace) return (int)hipErrorInvalidValue;
-    if (waves_per_stream != DEBIG_WAVES_SPLIT && waves_per_stream != DEBIG_WAVES_SPLIT_QUEUED) return (int)hipErrorInvalidValue;
+    if (waves_per_stream != DEBIG_WAVES_SPLIT && waves_per_stream != DEBIG_WAVES_SPLIT_QUEUED &&
+        waves_per_stream != DEBIG_WAVES_STRAND)
+        return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)hip_stream;
     DeviceGuard launch_guard(launch_device(s));
     const FixedTabs *ft = fixed_tables(s);
     if (!ft) return (int)hipErrorOutOfMemory;
     int rc = launch_split_group(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes, 2,
-                                waves_per_stream == DEBIG_WAVES_SPLIT_QUEUED);
+                                waves_per_stream == DEBIG_WAVES_SPLIT_QUEUED ? 1 : waves_per_stream == DEBIG_WAVES_STRAND ? 2 : 0);
     return rc < 0 ? (int)hipErrorInvalidValue : rc;
 }
 

@@ -133,6 +133,13 @@ int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d
  *              Never picked by 0: a batch sorted or grouped by kind / size is 2-4 % faster with
  *              DEBIG_WAVES_SPLIT.  DEBIG_SPLIT_WORKGROUPS overrides the number of resident workgroups. */
 #define DEBIG_WAVES_SPLIT_QUEUED 0x11u
+/*   DEBIG_WAVES_STRAND
+ *              DEBIG_WAVES_SPLIT with the long-segment scan (csrc/inflate_strand_kernel.inc): a lane decodes a
+ *              contiguous STRAND of a Huffman block as long as the block allows (a 64 KiB fixed-Huffman
+ *              stream: one window of 64 strands) from a per-lane input ring in LDS, keeps its tokens in one
+ *              pass, and only the lanes whose guessed start was wrong are decoded again, up to the point
+ *              where they rejoin their first decode.  Same workspace, same results. */
+#define DEBIG_WAVES_STRAND 0x12u
 /*   DEBIG_WAVES_CHUNKED
  *              a FEW LARGE streams (hundreds of big PNG images): every stream is cut at DEFLATE
  *              block boundaries into chunk tasks of 32..256 KiB of input, found by looking for

@@ -25,7 +25,11 @@ for _ in range(10):
         junk.add_(1)  # 2 GiB of traffic: evicts L2 and the 256 MiB Infinity Cache
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); b.launch(waves_per_stream=width); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
-res = b.results(); assert (res["good"] == 1).all() and (res["final_size"] == size).all()
-ok = all(b.output(i, res) == pairs[i][1].tobytes() for i in range(0, n, max(1, n // 32)))
+res = b.results()
+if os.environ.get("NOCHECK") == "1":  # timing-only builds (DEBIG_ABLATE): the output is wrong on purpose
+    ok = None
+else:
+    assert (res["good"] == 1).all() and (res["final_size"] == size).all()
+    ok = all(b.output(i, res) == pairs[i][1].tobytes() for i in range(0, n, max(1, n // 32)))
 ms = float(np.median(ts))
 print(f"{os.environ.get('DEBIG_LIB','default').split('/')[-1]:28s} {kind:8s} n={n:6d} width={width:#x} {ms:8.3f} ms  {n*size/ms/1e6:8.1f} GB/s  exact={ok} cold={cold}", flush=True)

@@ -3,7 +3,7 @@
 Builds two -DDEBIG_PROFILE libraries (one reports the scan kernel's phases, one the LZ77 kernel's)
 and runs each in a child process.  Shares only: instrumented builds run 3 waves per SIMD and are
 slower than the product; never quote their run time.
-usage: prof_split.py [kind=fixed] [n=4096] [size=65536]"""
+usage: prof_split.py [kind=fixed] [n=4096] [size=65536] [width=0x10 | 0x12]"""
 import os
 import subprocess
 import sys
@@ -17,15 +17,16 @@ sys.path.insert(0, %(root)r)
 import numpy as np, torch
 from debigulator_amd import workload
 from debigulator_amd.batch import DeviceBatch
-kind, n, size, which = %(kind)r, %(n)d, %(size)d, %(which)d
+kind, n, size, which, width = %(kind)r, %(n)d, %(size)d, %(which)d, %(width)d
 pairs = workload.make_streams(kind, n, size, threads=16)
 raws = [p[0] for p in pairs]; caps = [max(size + 1, len(r)) for r in raws]
 b = DeviceBatch.from_streams(raws, caps)
-for _ in range(3): b.launch(waves_per_stream=0x10)
+for _ in range(3): b.launch(waves_per_stream=width)
 torch.cuda.synchronize()
 res = b.results(); assert (res["good"] == 1).all()
 prof = res["prof"].astype(np.float64) * 16
-names = (["stage window", "position rounds", "full rounds (tokens)", "header + tables", "window records", "-", "TOTAL", "-"] if which == 0 else
+names = (["-", "lead (positions)", "main pass (tokens)", "header + tables", "chain + re-decode + records", "-", "TOTAL", "-"] if which == 0 and width == 0x12 else
+         ["stage window", "position rounds", "full rounds (tokens)", "header + tables", "window records", "-", "TOTAL", "-"] if which == 0 else
          ["token replay", "far copy", "near resolve", "flush", "-", "-", "TOTAL", "-"])
 tot = prof[:, 6].mean()
 print(f"{'scan kernel' if which == 0 else 'LZ77 kernel'}: {kind}, {n} streams x {size} B; windows/stream {res['n_windows'].mean():.2f}, "
@@ -45,7 +46,8 @@ if __name__ == "__main__":
     kind = sys.argv[1] if len(sys.argv) > 1 else "fixed"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     size = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
+    width = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0x10
     for which in (0, 1):
         lib = build(extra_defs=("DEBIG_PROFILE", f"DEBIG_PROFILE_LZ={which}"), out=f"libdebigulator_hip_prof{which}.so")
         env = dict(os.environ, DEBIG_LIB=lib)
-        subprocess.check_call([sys.executable, "-c", CHILD % {"root": ROOT, "kind": kind, "n": n, "size": size, "which": which}], env=env)
+        subprocess.check_call([sys.executable, "-c", CHILD % {"root": ROOT, "kind": kind, "n": n, "size": size, "which": which, "width": width}], env=env)

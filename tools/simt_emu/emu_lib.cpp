@@ -10,6 +10,7 @@
 #include "../../debigulator_amd/csrc/inflate_kernel.inc"
 #include "../../debigulator_amd/csrc/inflate_mw_kernel.inc"
 #include "../../debigulator_amd/csrc/inflate_split_kernel.inc"
+#include "../../debigulator_amd/csrc/inflate_strand_kernel.inc"
 #include "../../debigulator_amd/csrc/inflate_chunk_kernel.inc"
 #include "../../debigulator_amd/csrc/png_kernel.inc"
 #include "../../debigulator_amd/csrc/checksum_kernel.inc"
@@ -105,6 +106,8 @@ extern "C" int emu_inflate_split_batch(const void *in, void *out, const debig_st
             if (*q != (uint64_t)n) return -2; /* a launch adds exactly n to the queue counter */
             EMU_LAUNCH(debig_scanlz_queue_kernel, grid, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
             if (*q != 2u * (uint64_t)n) return -2;
+        } else if (getenv("DEBIG_EMU_STRAND")) { /* DEBIG_WAVES_STRAND: the long-segment scan */
+            EMU_LAUNCH(debig_strand_kernel, n, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
         } else {
             EMU_LAUNCH(debig_scanlz_kernel, n, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
         }
