@@ -26,10 +26,10 @@ def emu():
 
 
 # wavefronts per stream: 1 = debig_inflate_kernel, 2 / 4 = debig_inflate_mw_kernel<NW>
-@pytest.mark.parametrize("nw", [1, 2, 4, eb.SPLIT, eb.SPLIT_QUEUED])
+@pytest.mark.parametrize("nw", [1, 2, 4, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND])
 def test_known_answers_and_corpus(emu, nw):
     items = json.load(open(os.path.join(GOLD, "kat.json")))
-    items += json.load(open(os.path.join(GOLD, "corpus_zlib.json")))[:80 if nw in (1, eb.SPLIT, eb.SPLIT_QUEUED) else 40]
+    items += json.load(open(os.path.join(GOLD, "corpus_zlib.json")))[:80 if nw in (1, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND) else 40]
     raws = [bytes.fromhex(k["raw_hex"]) for k in items]
     caps = [k["recipient_size"] for k in items]
     outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, in_misalign=3, out_misalign=5)
@@ -44,10 +44,10 @@ def test_known_answers_and_corpus(emu, nw):
         assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
 
 
-@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.SPLIT_QUEUED])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND])
 def test_corrupt_corpus_reference_made(emu, nw):
     """tests/golden/corpus_corrupt.json: damaged streams with the REFERENCE's own answers (build B)"""
-    items = json.load(open(os.path.join(GOLD, "corpus_corrupt.json")))[:: 1 if nw in (1, eb.SPLIT, eb.SPLIT_QUEUED) else 3]
+    items = json.load(open(os.path.join(GOLD, "corpus_corrupt.json")))[:: 1 if nw in (1, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND) else 3]
     raws = [bytes.fromhex(k["raw_hex"]) for k in items]
     caps = [k["recipient_size"] for k in items]
     outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, out_misalign=1)
@@ -57,14 +57,14 @@ def test_corrupt_corpus_reference_made(emu, nw):
         assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
 
 
-@pytest.mark.parametrize("nw", [1, eb.SPLIT])
+@pytest.mark.parametrize("nw", [1, eb.SPLIT, eb.STRAND])
 @pytest.mark.parametrize("kind", ["stored", "fixed", "dynamic"])
 def test_cfg2_streams(emu, oracle, kind, nw):
     pairs = workload.make_streams(kind, 3, 65536)
     raws = [p[0] for p in pairs]
     caps = [max(65537, len(r)) for r in raws]
     outs, _, _ = eb.emu_inflate(emu, raws, caps, nw=nw)
-    if nw == eb.SPLIT:
+    if nw in (eb.SPLIT, eb.STRAND):
         assert eb.last_split_retried == 0  # the scan / LZ77 pair itself decoded them
     for (good, final, out, r), (raw, plain) in zip(outs, pairs):
         assert (good, final) == (1, 65536) and out == plain.tobytes()
@@ -104,7 +104,7 @@ def test_multi_wavefront_kernel_crosses_windows_and_tiles(emu):
     assert r.n_windows >= 2
 
 
-@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND])
 def test_end_position_and_no_gates_flag(emu, nw):
     """debig_result.in_end_bits (where decoding stopped) and DEBIG_STREAM_NO_REF_GATES: what a
     container with several members needs (debig_gunzip_batch).  A raw stream followed by other
@@ -158,7 +158,7 @@ def _tiny_block_streams(seed, count, max_len):
     return raws, caps
 
 
-@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND])
 def test_streams_of_tiny_blocks_take_the_probe_path(emu, oracle, nw):
     raws, caps = _tiny_block_streams(31 + nw, 12 if nw == 1 else 6, 1500)
     outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, in_misalign=5, out_misalign=11)
@@ -190,7 +190,7 @@ def test_mixed_width_launches_partition_the_batch(emu, oracle):
     assert [r.final_set for _, _, _, r in only_large] == [it % 2 for it in range(10)]
 
 
-@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND])
 def test_corrupt_streams_agree_with_oracle(emu, oracle, nw):
     rng = random.Random(4)
     raws, caps = [], []
@@ -211,7 +211,7 @@ def test_corrupt_streams_agree_with_oracle(emu, oracle, nw):
         assert (good, final, out) == (eg, ef, eo)
 
 
-@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND])
 def test_p2_aliasing_replay_matches_reference_digest(emu, nw):
     """phoebus.png: the inflate kernel with the decode_png aliasing parameters + the
     de-filter kernel reproduce the reference's (corrupted-tail) output."""
@@ -476,7 +476,7 @@ raws = [bytes.fromhex(k["raw_hex"]) for k in items]; caps = [k["recipient_size"]
 for kind, size in (("stored", 5000), ("dynamic", 9000), ("fixed", 3000)):
     raw, plain = workload.make_stream(kind, 3, size)
     raws.append(raw); caps.append(max(size + 1, len(raw))); items.append({"good": 1, "final": size, "plain": plain.tobytes()})
-for nw in (1, 4, eb.SPLIT, eb.CHUNKED):
+for nw in (1, 4, eb.SPLIT, eb.STRAND, eb.CHUNKED):
     outs, arena, offs = eb.emu_inflate(L, raws, caps, nw=nw, in_misalign=1, out_misalign=3, chunk_bytes=1024)
     for k, (good, final, out, r) in zip(items, outs):
         assert good == k["good"] and final == k["final"], (nw, k.get("name"))
@@ -510,8 +510,10 @@ def test_split_path_hands_back_what_does_not_fit_its_workspace(emu, oracle):
     caps.append(len(dense) + 1)
     want = [oracle.inflate(r, c) for r, c in zip(raws, caps)]
     seen = set()
-    for ws in (None, 9 * sum(len(r) for r in raws) // 6, 40 * 1024, len(raws) * 1024 + 4096):
-        outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=eb.SPLIT, ws_bytes=ws, out_misalign=3)
+    for ws, nw in ((None, eb.SPLIT), (9 * sum(len(r) for r in raws) // 6, eb.SPLIT), (40 * 1024, eb.SPLIT),
+                   (len(raws) * 1024 + 4096, eb.SPLIT), (None, eb.STRAND), (9 * sum(len(r) for r in raws) // 6, eb.STRAND),
+                   (40 * 1024, eb.STRAND)):
+        outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, ws_bytes=ws, out_misalign=3)
         seen.add(eb.last_split_retried)
         for (good, final, out, r), w in zip(outs, want):
             assert (good, final, out) == w
@@ -521,7 +523,7 @@ def test_split_path_hands_back_what_does_not_fit_its_workspace(emu, oracle):
     assert max(seen) >= len(raws) - 1
 
 
-@pytest.mark.parametrize("nw", [1, 2, 8, eb.SPLIT])
+@pytest.mark.parametrize("nw", [1, 2, 8, eb.SPLIT, eb.STRAND])
 def test_long_codes_take_the_second_level_tables(emu, oracle, nw):
     """Codes longer than the direct tables (10/11 bits literal/length, 9 bits distance) are decoded
     through second-level tables linked from the direct table (CodeTabsT::sub_tab): geometric byte
@@ -773,7 +775,7 @@ def test_chunked_path_random_streams_agree_with_oracle(emu, oracle, seed, chunk)
         assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
 
 
-@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND])
 def test_randomised_dynamic_headers(emu, oracle, nw):
     """tests/header_fuzz.py: random prefix codes and a randomised run-length coding of the code-length
     sequence (16 at the start, runs across the alphabets, runs that reach behind the last length,
@@ -797,3 +799,43 @@ def test_randomised_dynamic_headers(emu, oracle, nw):
         elif plain is None:
             n_damaged += 1
     assert n_plain > len(cs) // 2 and n_damaged > len(cs) // 8
+
+
+def test_strand_path_random_zlib_streams(emu, oracle):
+    """DEBIG_WAVES_STRAND (csrc/inflate_strand_kernel.inc) on zlib streams of every strategy and level: many blocks
+    per stream, blocks shorter than a strand, windows whose lanes are decoded again in several rounds (a lane that
+    was decoded to its end from a wrong start and joins its first decode a round later), probes, stored blocks in
+    between -- against the oracle."""
+    rng = random.Random(1234)
+    raws, caps = [], []
+    for it in range(160):
+        n = rng.randint(1, 30000)
+        kind = rng.randint(0, 3)
+        if kind == 0:
+            data = bytes(rng.getrandbits(8) for _ in range(n))
+        elif kind == 1:
+            data = bytes(rng.choice(b"abcdefgh \n") for _ in range(n))
+        elif kind == 2:
+            words = [bytes(rng.getrandbits(8) for _ in range(rng.randint(2, 9))) for _ in range(rng.randint(5, 300))]
+            data = b"".join(rng.choice(words) for _ in range(n // 5 + 1))[:n]
+        else:
+            data = bytes((i * 7 + (i >> 5)) & 255 for i in range(n))
+        strat = rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED])
+        c = zlib.compressobj(rng.choice([1, 6, 9]), zlib.DEFLATED, -15, rng.choice([1, 8, 9]), strat)
+        raw = b""
+        pos = 0
+        while pos < len(data):  # flushes cut the stream into blocks of every size
+            step = rng.choice([len(data), 50, 700, 5000])
+            raw += c.compress(data[pos:pos + step])
+            if rng.random() < 0.5:
+                raw += c.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH]))
+            pos += step
+        raw += c.flush()
+        raws.append(raw)
+        caps.append(max(len(data) + 1, len(raw)))
+    outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=eb.STRAND, in_misalign=5, out_misalign=9)
+    for raw, cap, (good, final, out, r) in zip(raws, caps, outs):
+        eg, ef, eo, st = oracle.inflate(raw, cap, want_stats=True)
+        if st.ub_flags & (0x10 | 0x02):
+            continue
+        assert (good, final, out) == (eg, ef, eo)

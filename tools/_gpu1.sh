@@ -1,5 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python tools/ab_variants.py run kinds=fixed,dynamic width=0x12
-for w in 0x10 0x12; do python tools/bench_variant.py dynamic 2048 $w 1048576 | tail -1; done
-for w in 0x10 0x12; do python tools/bench_variant.py fixed 8192 $w 65536 | tail -1; done
-for w in 0x10 0x12; do python tools/bench_variant.py fixed 16384 $w 65536 | tail -1; done
+timeout -k 10 1700 python -m pytest tests/test_gpu_inflate.py tests/test_gpu_configs.py tests/test_gpu_dropin.py -x -q 2>&1 | tail -8
