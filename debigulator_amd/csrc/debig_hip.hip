@@ -520,6 +520,32 @@ static uint32_t defilter_waves(uint32_t n)
     return 1u;
 }
 
+// workgroups of the several-workgroups-per-image de-filter (wpw wavefronts each) that device `dev` holds at once
+static uint32_t mwg_resident_workgroups(int dev, uint32_t wpw)
+{
+    const char *e = getenv("DEBIG_DEFILTER_RESIDENT"); /* tests: read at every call */
+    if (e && *e) return (uint32_t)strtoul(e, nullptr, 0);
+    if (dev < 0 || dev >= 64) return 0u;
+    static std::mutex m;
+    static uint32_t cap[64][3]; /* wpw = 2, 4, 8 */
+    const int k = wpw == 2u ? 0 : wpw == 4u ? 1 : 2;
+    std::lock_guard<std::mutex> lock(m);
+    if (cap[dev][k] == 0) {
+        DeviceGuard guard(dev);
+        int per_cu = 0, cus = 0;
+        hipError_t rc = k == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, debig_png_defilter_kernel<2, 16, true>, 128, 0)
+                        : k == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, debig_png_defilter_kernel<4, 16, true>, 256, 0)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, debig_png_defilter_kernel<8, 16, true>, 512, 0);
+        if (rc != hipSuccess || per_cu <= 0) per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 0;
+        // one workgroup per CU is what the measured shapes assume (and what 8 wavefronts' LDS allows); a device
+        // that would hold two is still asked for one
+        cap[dev][k] = per_cu > 0 ? (uint32_t)cus : 1u; /* never 0: asked once */
+        if (per_cu == 0 || cus == 0) cap[dev][k] = 1u;
+    }
+    return cap[dev][k];
+}
+
 int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena,
                                  const debig_png_image *d_images, debig_png_result *d_results,
                                  uint32_t n, void *hip_stream)
@@ -548,7 +574,14 @@ int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena
         if (env_w == 2u || env_w == 4u || env_w == 8u) wpw = env_w;
         if (g > 8u) g = 8u;
         if (g * wpw > PNG_GSYNC_STRIDE - 16u) g = (PNG_GSYNC_STRIDE - 16u) / wpw; /* progress words per image */
-        DefaultWs *gw = g > 1u && (uint64_t)n * g <= 256u ? png_gsync(s, n) : nullptr;
+        // all n * G workgroups must be resident TOGETHER (the bands of an image are a ring of dependencies): the limit
+        // is what THIS device holds of THIS instantiation (its CU count x the runtime's occupancy answer), not a
+        // constant -- a partitioned device, a CU mask or a smaller part holds fewer.  G is halved until the grid
+        // fits; when even G = 2 does not, the one-workgroup-per-image launch below takes the batch.
+        // DEBIG_DEFILTER_RESIDENT overrides the limit (tests).
+        const uint32_t resident = mwg_resident_workgroups(launch_device(s), wpw);
+        while (g > 1u && (uint64_t)n * g > resident) g >>= 1;
+        DefaultWs *gw = g > 1u ? png_gsync(s, n) : nullptr;
         if (gw) {
             SharedWsUse hold(gw, s);
             uint32_t *gsync = (uint32_t *)gw->ptr;
@@ -556,13 +589,23 @@ int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena
             if (e != hipSuccess) return (int)e;
             if (wpw == 8u)
                 hipLaunchKernelGGL((debig_png_defilter_kernel<8, 16, true>), dim3(n * g), dim3(512), 0, s,
-                                   (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n, g, gsync);
+                                   (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n, g, gsync, 0u);
             else if (wpw == 2u)
                 hipLaunchKernelGGL((debig_png_defilter_kernel<2, 16, true>), dim3(n * g), dim3(128), 0, s,
-                                   (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n, g, gsync);
+                                   (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n, g, gsync, 0u);
             else
                 hipLaunchKernelGGL((debig_png_defilter_kernel<4, 16, true>), dim3(n * g), dim3(256), 0, s,
-                                   (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n, g, gsync);
+                                   (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n, g, gsync, 0u);
+            // Residency is the runtime's promise, not a guarantee (another stream's kernels may hold LDS when this
+            // grid starts): a workgroup that waited in vain gave its image up as REDO after some tens of milliseconds,
+            // and this launch -- one workgroup per image, nothing to wait for across workgroups -- decodes exactly
+            // those images again.  Normally every workgroup finds nothing to do and leaves at once (a few us).
+            if (n <= 64u)
+                hipLaunchKernelGGL((debig_png_defilter_kernel<16, 6>), dim3(n), dim3(1024), 0, s, (const uint8_t *)d_streams_arena,
+                                   (uint8_t *)d_rgba_arena, d_images, d_results, n, 1u, (uint32_t *)nullptr, 1u);
+            else
+                hipLaunchKernelGGL((debig_png_defilter_kernel<8>), dim3(n), dim3(512), 0, s, (const uint8_t *)d_streams_arena,
+                                   (uint8_t *)d_rgba_arena, d_images, d_results, n, 1u, (uint32_t *)nullptr, 1u);
             hipLaunchKernelGGL(debig_png_p3_kernel, dim3(n), dim3(PNG_P3_THREADS), 0, s,
                                (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n);
             return (int)hipGetLastError();

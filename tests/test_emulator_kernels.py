@@ -365,6 +365,54 @@ def test_defilter_kernel_several_wavefronts_per_image(emu, nwd):
     assert _emu_defilter(emu, stream.tobytes(), w, h, 6, nwd=nwd, expect_good=0) == 70
 
 
+def test_defilter_workgroups_of_an_image_never_resident_together(emu):
+    """The several-workgroups-per-image de-filter (debig_png_defilter_kernel<4, 16, true>) needs an image's
+    workgroups resident together; when they are not (fewer CUs than assumed, another stream's kernels holding
+    LDS -- here: the emulator, which runs ONE workgroup at a time) a workgroup that waits in vain gives the
+    image up as REDO, never as bad (src/decode_png.c:1430-1507 does not fail a valid image), and the
+    one-workgroup pass that follows decodes exactly those images: the pixels are the specification's, a row
+    with a bad filter byte still fails its image with the first bad row."""
+    emu.emu_png_defilter_mwg.restype = C.c_int
+    emu.emu_png_defilter_mwg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                         C.POINTER(C.c_uint32)]
+    rng = np.random.default_rng(77)
+    shapes = [(6, 300, 64 * 9 + 5, None), (2, 90, 64 * 5 + 3, None), (6, 40, 700, 650), (6, 33, 40, None)]
+    n = len(shapes)
+    streams, exps = [], []
+    for ct, w, h, bad in shapes:
+        bpp = {6: 4, 2: 3}[ct]
+        st = rng.integers(0, 256, h * (w * bpp + 1), dtype=np.uint8)
+        st[:: w * bpp + 1] = rng.integers(0, 5, h)
+        want = _spec_defilter(st, w, h, bpp).reshape(h, w, bpp)
+        if ct == 2:
+            want = np.concatenate([want, np.full((h, w, 1), 255, np.uint8)], axis=2)
+        if bad is not None:
+            st[bad * (w * bpp + 1)] = 7
+        streams.append(st)
+        exps.append(want)
+    sa = np.zeros(sum(len(s) + 32 for s in streams) + 1024, dtype=np.uint8)
+    rgba = np.zeros(sum(4 * w * h + 64 for _, w, h, _ in shapes), dtype=np.uint8)
+    img = (DebigPngImage * n)()
+    res = (DebigPngResult * n)()
+    so, ro = 3, 0
+    for i, ((ct, w, h, bad), st) in enumerate(zip(shapes, streams)):
+        sa[so:so + len(st)] = st
+        img[i].stream_off, img[i].rgba_off, img[i].pal_off = so, ro, 0
+        img[i].width, img[i].height, img[i].color_type, img[i].asserts_off = w, h, ct, 0
+        so += len(st) + 29
+        ro += 4 * w * h + 64
+    n_redo = C.c_uint32(0)
+    assert emu.emu_png_defilter_mwg(sa.ctypes.data, rgba.ctypes.data, img, res, n, 4, C.byref(n_redo)) == 0
+    assert n_redo.value >= 2  # the images with more bands than one workgroup's wavefronts were given up first ...
+    for i, ((ct, w, h, bad), want) in enumerate(zip(shapes, exps)):
+        if bad is not None:  # ... a real bad row is still a failed image
+            assert (res[i].good, res[i].bad_row) == (0, bad)
+            continue
+        assert res[i].good == 1, i  # ... and came back as the specification's pixels
+        got = rgba[img[i].rgba_off: img[i].rgba_off + 4 * w * h].reshape(h, w, 4)
+        assert np.array_equal(got, want), i
+
+
 def test_p3_rgb_replay_kernel_matches_reference_digest(emu):
     """colour type 2 through debig_png_p3_kernel on the emulator: a small synthetic RGB image
     against the oracle (pinned to the reference on this behaviour by backgrounddetailed1.png)."""

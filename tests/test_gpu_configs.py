@@ -142,6 +142,45 @@ def test_defilter_several_workgroups_per_image(gpu_device, oracle, n):
     assert all(ires[i]["good"] == 1 for i in range(n) if i != 1)
 
 
+def test_defilter_workgroups_not_resident_together_fall_back(gpu_device, oracle):
+    """The several-workgroups-per-image de-filter when its residency assumption does NOT hold: 64 images x 8
+    workgroups of 4 wavefronts (87 KB of LDS each: one per CU) are twice what the device holds at once
+    (DEBIG_DEFILTER_WGS / DEBIG_DEFILTER_RESIDENT force the shape past the shim's own limit).  Workgroups that
+    wait in vain give their image up as REDO within tens of milliseconds and the one-workgroup pass of the same
+    call decodes those images: every image comes back good and with the oracle's pixels -- a valid PNG never
+    turns into good = 0 (src/decode_png.c:1430-1507).  In a child process: the shape overrides are read once."""
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+from debigulator_amd import workload
+from debigulator_amd.png_device import DevicePngBatch
+from oracle.binding import Oracle
+oracle = Oracle()
+n = 64
+pngs, want = [], []
+for i in range(n):
+    w, h = ((97, 900), (260, 700), (64, 1300), (130, 520))[i %% 4]
+    png, pix = workload.make_png(900 + i, w, h, ct=6, ftype=(5, 4, 3, 1, 2)[i %% 5], noise=6, enc="dynamic")
+    pngs.append(png)
+    if i < 8: want.append(oracle.decode_png(png))
+b = DevicePngBatch(pngs, device=%(dev)r)
+b.launch()
+res, ires = b.results()
+assert (res["good"] == 1).all(), "inflate"
+assert (ires["good"] == 1).all(), [(i, int(ires[i]["bad_row"])) for i in range(n) if ires[i]["good"] != 1][:5]
+for i in range(8):
+    g, px = want[i]
+    assert g == 1 and np.array_equal(b.rgba(i).reshape(-1), np.asarray(px).reshape(-1)), i
+print("fallback ok")
+""" % {"root": os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dev": gpu_device}
+    env = dict(os.environ, DEBIG_DEFILTER_WGS="8", DEBIG_DEFILTER_RESIDENT="1000000")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "fallback ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
 def test_cfg5_shape_gzip_members(gpu_device, oracle):
     """gzip members of 1 MiB (text-like, dynamic Huffman, EOB >= 8 bits so the tail rule never
     truncates): header located on the host, payloads inflated in one launch."""

@@ -203,6 +203,25 @@ extern "C" int emu_png_defilter_batch_w(const void *streams_arena, void *rgba_ar
                results, n);
     return 0;
 }
+/* the several-workgroups-per-image mode as the shim launches it: G workgroups of 4 wavefronts per image, then the
+ * one-workgroup pass over the images given up as REDO.  The emulator runs ONE workgroup at a time, i.e. the
+ * workgroups of an image are never resident together: every cross-workgroup wait fails, which is exactly the
+ * situation the REDO pass exists for.  *n_redo = images the first launch gave up. */
+extern "C" int emu_png_defilter_mwg(const void *streams_arena, void *rgba_arena, const debig_png_image *images,
+                                    debig_png_result *results, uint32_t n, uint32_t g, uint32_t *n_redo)
+{
+    uint32_t *gsync = (uint32_t *)calloc((size_t)n * PNG_GSYNC_STRIDE, sizeof(uint32_t));
+    EMU_LAUNCH((debig_png_defilter_kernel<4, 16, true>), n * g, 256, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images,
+               results, n, g, gsync, 0u);
+    uint32_t redo = 0;
+    for (uint32_t i = 0; i < n; i++) redo += results[i].good == 0 && results[i].bad_row == PNG_ROW_REDO;
+    if (n_redo) *n_redo = redo;
+    EMU_LAUNCH((debig_png_defilter_kernel<16, 6>), n, 1024, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images, results, n,
+               1u, (uint32_t *)nullptr, 1u);
+    EMU_LAUNCH(debig_png_p3_kernel, n, PNG_P3_THREADS, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images, results, n);
+    free(gsync);
+    return 0;
+}
 extern "C" int emu_png_defilter_batch(const void *streams_arena, void *rgba_arena, const debig_png_image *images,
                                       debig_png_result *results, uint32_t n)
 {
