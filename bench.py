@@ -382,9 +382,21 @@ def main():
 
     # ---- CPU baseline first (rank 0, any N): nothing has touched the GPU or torch.distributed yet
     cpu_line = None
+    cpu5_line = None  # the reference on config 5's data (dynamic Huffman, 1 MiB members): beside cfg5_strong
     if not cfg4 and rank == 0 and not args.no_cpu_baseline:
         samples, sample_label = early_samples(args)
         cpu_line = run_cpu_baseline(args, rank, samples, sample_label)
+        if not cfg5 and not args.no_cfg5:
+            try:
+                a5 = argparse.Namespace(**vars(args))
+                a5.config = "cfg5"
+                s5, l5 = early_samples(a5)
+                eng, kind = _cpu_engine()
+                v, passes, dt = _cpu_timed(eng, s5["gzip_dynamic"], 5.0)
+                cpu5_line = {"value": v, "unit": "GB/s decompressed", "cores": 1, "kind": kind,
+                             "sample": f"{l5}; whole passes, 1 thread, {dt:.1f} s ({passes} passes)"}
+            except Exception as e:  # a report, never a reason to lose the GPU number
+                cpu5_line = {"value": None, "unit": "GB/s decompressed", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
 
     import numpy as np
     import torch
@@ -572,6 +584,37 @@ def main():
             name = "roofline_huffman" if kind == "fixed" else "roofline_stored"
             line[name] = roof(cb, db, ms, f"{kind} streams launched alone ({len(r)} x 64 KiB), same kernels",
                               2 if len(r) > 1024 else 1)
+        if not cfg4 and not cfg5 and split and len(res) <= 16384:
+            # (a) the timed steps run over a workspace carved ONCE (DeviceBatch: debig_hip_inflate_plan_ws before the
+            # warm-up); a caller of debig_hip_inflate_batch(_ws) with fresh descriptors pays debig_split_plan_kernel
+            # on every call: the same step with the plan kernel in it
+            def launch_with_plan():
+                batch._planned = False
+                batch.launch()
+
+            for _ in range(2):
+                launch_with_plan()
+            ms_plan = time_launches(torch, launch_with_plan, 20)
+            verify()
+            rl["plan_in_timed_region"] = False
+            rl["ms_with_plan"] = ms_plan
+            rl["frac_with_plan"] = (c_bytes + d_bytes) / (ms_plan * 1e-3) / 1e9 / HBM_PEAK_GBS
+            # (b) the headline parks all Huffman streams in front of all stored ones (the measured best order: one
+            # workgroup per stream is dealt to the shader engines by index).  The same streams ALTERNATING kinds
+            # through the same default dispatch: what a caller who does not sort by kind gets
+            order = [i // 2 + (per if i % 2 else 0) for i in range(2 * per)]
+            ib = DeviceBatch.from_streams([raws[i] for i in order], [caps[i] for i in order], device=dev)
+            for _ in range(2):
+                ib.launch()
+            ms_il = time_launches(torch, ib.launch, 20)
+            ri = ib.results()
+            assert (ri["good"] == 1).all() and (ri["final_size"] == STREAM_BYTES).all()
+            for k in (0, 1, 2 * per - 2, 2 * per - 1):
+                assert ib.output(k, ri) == all_pairs[order[k]][1].tobytes(), f"interleaved stream {k} differs"
+            line["roofline_interleaved"] = roof(c_bytes, d_bytes, ms_il,
+                                                "the same streams, kinds alternating (fixed, stored, fixed, ...), default "
+                                                "dispatch (DEBIG_WAVES_SPLIT): order sensitivity of one workgroup per stream", 2)
+            del ib
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
 
@@ -602,6 +645,8 @@ def main():
                 "bit_exact_checked": "every member's size/good flag + CRC-32 (on the GPU), 3 members byte for byte",
                 "roofline": r5,
             }
+            if cpu5_line is not None:
+                line["cfg5_strong"]["cpu_baseline"] = cpu5_line
         del b5
     if rank == 0:
         print(json.dumps(line), flush=True)

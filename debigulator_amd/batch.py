@@ -150,16 +150,21 @@ class DeviceBatch:
             if self.n <= 16384:
                 # the descriptors and the workspace are this object's own and never change: the workspace
                 # is carved once (debig_hip_inflate_plan_ws), every launch is scan + LZ77 only
-                if not getattr(self, "_planned", False):
-                    N.check(self.lib.debig_hip_inflate_plan_ws(self.d_streams.data_ptr(), self.n, ws_ptr, ws_bytes,
-                                                               C.c_void_p(stream.cuda_stream)), "debig_hip_inflate_plan_ws")
-                    self._planned = True
-                N.check(self.lib.debig_hip_inflate_planned_ws_ex(self.d_in.data_ptr(), self.d_out.data_ptr(),
-                                                                 self.d_streams.data_ptr(), self.d_results.data_ptr(), self.n,
-                                                                 waves_per_stream or N.WAVES_SPLIT,
-                                                                 ws_ptr, ws_bytes, C.c_void_p(stream.cuda_stream)),
-                        "debig_hip_inflate_planned_ws_ex")
-                return
+                # (the plan kernel runs on ONE stream: a launch on another stream plans again there -- cheaper
+                # than an event chain, and the slots are only ever carved to the same values)
+                if not getattr(self, "_planned", False) or getattr(self, "_plan_stream", None) != stream.cuda_stream:
+                    rc = self.lib.debig_hip_inflate_plan_ws(self.d_streams.data_ptr(), self.n, ws_ptr, ws_bytes,
+                                                            C.c_void_p(stream.cuda_stream))
+                    self._planned = rc == 0
+                    self._plan_stream = stream.cuda_stream
+                if self._planned:
+                    N.check(self.lib.debig_hip_inflate_planned_ws_ex(self.d_in.data_ptr(), self.d_out.data_ptr(),
+                                                                     self.d_streams.data_ptr(), self.d_results.data_ptr(), self.n,
+                                                                     waves_per_stream or N.WAVES_SPLIT,
+                                                                     ws_ptr, ws_bytes, C.c_void_p(stream.cuda_stream)),
+                            "debig_hip_inflate_planned_ws_ex")
+                    return
+                # a workspace too small to plan: debig_hip_inflate_batch_ws below falls back to the one-kernel path
         rc = self.lib.debig_hip_inflate_batch_ws(self.d_in.data_ptr(), self.d_out.data_ptr(),
                                                  self.d_streams.data_ptr(), self.d_results.data_ptr(),
                                                  self.n, waves_per_stream, ws_ptr, ws_bytes,

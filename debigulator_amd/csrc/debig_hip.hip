@@ -147,22 +147,38 @@ struct DefaultWs {
     int has_done;
 };
 static DefaultWs g_default_ws[64];
-struct SharedWsUse { /* RAII over one call's launches on the default workspace (nullptr: caller-owned workspace) */
+struct SharedWsUse { /* one call's launches on the default workspace (nullptr: caller-owned workspace) */
     DefaultWs *w;
     hipStream_t s;
-    SharedWsUse(DefaultWs *w_, hipStream_t s_) : w(w_), s(s_)
+    int err; /* hipError_t of the wait in front of the launches (0: the group before this one is ordered before us) */
+    bool finished;
+    SharedWsUse(DefaultWs *w_, hipStream_t s_) : w(w_), s(s_), err(0), finished(false)
     {
         if (!w) return;
         w->use.lock();
-        if (w->has_done) (void)hipStreamWaitEvent(s, w->done, 0);
+        if (w->has_done) err = (int)hipStreamWaitEvent(s, w->done, 0);
     }
-    ~SharedWsUse()
+    // records the event the next group waits for; returns its hipError_t.  A stream that is being captured into
+    // a graph cannot carry this chain (the event would belong to the capture): callers that capture bring their
+    // own workspace (include/debig_hip.h), and a failure here is REPORTED instead of silently dropping the
+    // serialisation of the shared buffer
+    int finish()
     {
-        if (!w) return;
-        if (!w->has_done && hipEventCreateWithFlags(&w->done, hipEventDisableTiming) == hipSuccess) w->has_done = 1;
-        if (w->has_done) (void)hipEventRecord(w->done, s);
+        if (!w || finished) return 0;
+        finished = true;
+        int rc = 0;
+        if (!w->has_done) {
+            rc = (int)hipEventCreateWithFlags(&w->done, hipEventDisableTiming);
+            if (rc == 0) w->has_done = 1;
+        }
+        if (w->has_done) {
+            const int r2 = (int)hipEventRecord(w->done, s);
+            if (rc == 0) rc = r2;
+        }
         w->use.unlock();
+        return rc;
     }
+    ~SharedWsUse() { (void)finish(); }
 };
 static DefaultWs *default_workspace(hipStream_t s)
 {
@@ -191,11 +207,13 @@ static DefaultWs *default_workspace(hipStream_t s)
 static uint32_t scanlz_resident_workgroups()
 {
     static uint32_t cap[64];
+    static std::mutex cap_mutex; /* concurrent callers (the drop-in API allows 10 thread ids) */
     const char *e = getenv("DEBIG_SPLIT_WORKGROUPS"); /* tests and experiments: read at every call */
     const uint32_t forced = e && *e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
     if (forced) return forced;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 4096u;
+    std::lock_guard<std::mutex> lock(cap_mutex);
     if (cap[dev] == 0) {
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, debig_scanlz_queue_kernel, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
@@ -379,7 +397,10 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
         int rc = -1;
         if (d_workspace) {
             SharedWsUse hold(shared, s);
+            if (hold.err) return hold.err;
             rc = launch_chunked(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes);
+            const int frc = hold.finish();
+            if (rc == 0 && frc) return frc;
         }
         if (rc >= 0) return rc;
         d_workspace = nullptr;
@@ -395,8 +416,11 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
         int rc = -1;
         if (d_workspace) {
             SharedWsUse hold(shared, s);
+            if (hold.err) return hold.err;
             rc = launch_split(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes,
                               waves_per_stream == DEBIG_WAVES_SPLIT_QUEUED ? 1 : waves_per_stream == DEBIG_WAVES_STRAND ? 2 : 0);
+            const int frc = hold.finish();
+            if (rc == 0 && frc) return frc;
         }
         if (rc >= 0) return rc;
         waves_per_stream = 1; /* no usable workspace: the one-kernel path */
@@ -584,6 +608,7 @@ int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena
         DefaultWs *gw = g > 1u ? png_gsync(s, n) : nullptr;
         if (gw) {
             SharedWsUse hold(gw, s);
+            if (hold.err) return hold.err;
             uint32_t *gsync = (uint32_t *)gw->ptr;
             hipError_t e = hipMemsetAsync(gsync, 0, (size_t)n * PNG_GSYNC_STRIDE * sizeof(uint32_t), s);
             if (e != hipSuccess) return (int)e;
@@ -608,7 +633,9 @@ int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena
                                    (uint8_t *)d_rgba_arena, d_images, d_results, n, 1u, (uint32_t *)nullptr, 1u);
             hipLaunchKernelGGL(debig_png_p3_kernel, dim3(n), dim3(PNG_P3_THREADS), 0, s,
                                (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n);
-            return (int)hipGetLastError();
+            const int lrc = (int)hipGetLastError();
+            const int frc = hold.finish();
+            return lrc ? lrc : frc;
         }
     }
 #define DEFILTER_LAUNCH(W)                                                                              \

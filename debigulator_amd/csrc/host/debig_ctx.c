@@ -59,22 +59,31 @@ void debig_ctx_release_ptr(debig_ctx *c)
 }
 
 /* ---- page-locked staging */
-/* The arenas are reused from call to call, but not hoarded: one that is more than 4 x what the call
- * needs and larger than 256 MiB is given back first (10 thread ids x up to 16 device contexts each
- * keep a pair of them). */
+/* The arenas are reused from call to call, but not hoarded: one that is more than 4 x what the calls
+ * need and larger than 256 MiB is given back (10 thread ids x up to 16 device contexts each keep a pair
+ * of them) -- but only after DEBIG_PIN_SMALL_CALLS such calls IN A ROW: a caller that alternates large and
+ * small batches must not free and page-lock hundreds of MiB again on every call of the drop-in API
+ * (hipHostMalloc costs milliseconds per GiB). */
 #define DEBIG_PIN_KEEP (256ull << 20)
+#define DEBIG_PIN_SMALL_CALLS 8u
 static int pin_reserve(debig_devbuf *b, uint64_t bytes)
 {
     if (b->ptr && b->cap > DEBIG_PIN_KEEP && b->cap / 4u > bytes) {
-        debig_hip_host_free(b->ptr);
-        b->ptr = NULL;
-        b->cap = 0;
+        if (++b->small_calls >= DEBIG_PIN_SMALL_CALLS) {
+            debig_hip_host_free(b->ptr);
+            b->ptr = NULL;
+            b->cap = 0;
+            b->small_calls = 0;
+        }
+    } else {
+        b->small_calls = 0;
     }
     if (b->cap >= bytes && b->ptr) return 0;
     if (b->ptr) debig_hip_host_free(b->ptr);
     uint64_t cap = bytes + bytes / 4 + 4096;
     b->ptr = debig_hip_host_alloc(cap);
     b->cap = b->ptr ? cap : 0;
+    b->small_calls = 0;
     return b->ptr ? 0 : 2;
 }
 

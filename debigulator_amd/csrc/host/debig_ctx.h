@@ -13,6 +13,7 @@
 typedef struct debig_devbuf {
     void *ptr;
     uint64_t cap;
+    uint32_t small_calls; /* page-locked arenas: consecutive calls that needed less than a quarter of it */
 } debig_devbuf;
 
 typedef struct debig_ctx {

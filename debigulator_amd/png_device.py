@@ -47,7 +47,7 @@ class DevicePngBatch:
         p2 = None if strict else [(e - 772 + ((16 - (e & 15)) & 15), e) for e in ests]
         in_arena, streams, out_bytes = pack_streams(raws, ests, p2=p2)
         # palettes live behind the stream arena
-        pal_base = out_bytes
+        pal_base = self.pal_base = out_bytes  # d_out[:pal_base]: the scanline streams
         self.inflate = DeviceBatch(in_arena, streams, out_bytes + 768 * n + 64, device, plan=True)
         img = (N.DebigPngImage * n)()
         off = 0
@@ -72,11 +72,12 @@ class DevicePngBatch:
         self.d_ires = torch.zeros(n * C.sizeof(N.DebigPngResult), dtype=torch.uint8, device=device)
         self.lib = N.lib()
 
-    def launch(self, stream=None):
+    def launch(self, stream=None, waves_per_stream=0):
+        """waves_per_stream: inflate width (include/debig_hip.h: debig_hip_inflate_batch_ex), 0 = the batch's own plan"""
         torch = self.torch
         if stream is None:
             stream = torch.cuda.current_stream(self.inflate.device)
-        self.inflate.launch(stream)
+        self.inflate.launch(stream, waves_per_stream=waves_per_stream)
         rc = self.lib.debig_hip_png_defilter_batch(self.inflate.d_out.data_ptr(), self.d_rgba.data_ptr(),
                                                    self.d_img.data_ptr(), self.d_ires.data_ptr(), self.n,
                                                    C.c_void_p(stream.cuda_stream))

@@ -121,7 +121,12 @@ int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d
  *              at 3 wavefronts per SIMD instead of 2.  Needs device workspace
  *              (debig_hip_inflate_batch_ws; debig_hip_inflate_batch / _ex use a cached internal
  *              one of DEBIG_WORKSPACE_MB MiB, default 1024); a stream that does not fit its share
- *              is decoded by the one-kernel path in the same call. */
+ *              is decoded by the one-kernel path in the same call.
+ *              ORDER MATTERS: one workgroup per stream is dealt to the shader engines by index, whatever it
+ *              costs.  A batch sorted or grouped by kind / size (all Huffman streams, then all stored ones: what
+ *              bench.py times) is the good case; the same streams alternating kinds run up to 1.8 x slower
+ *              (bench.py reports both: roofline and roofline_interleaved).  Callers that cannot group their
+ *              descriptors use DEBIG_WAVES_SPLIT_QUEUED. */
 #define DEBIG_WAVES_SPLIT 0x10u
 /*   DEBIG_WAVES_SPLIT_QUEUED
  *              DEBIG_WAVES_SPLIT for a batch whose ORDER mixes cheap and expensive streams (stored and

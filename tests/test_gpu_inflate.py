@@ -232,50 +232,33 @@ def test_large_streams_every_width(gpu_device):
 
 
 def test_p2_aliasing_replay_every_width(gpu_device):
-    """decode_png's buffer-aliasing replay (parameters p2_s0 / p2_est of
-    debig_stream) is part of the inflate kernel: all widths must produce the same, replayed,
-    stream.  This test only says "all widths agree"; the replayed bytes themselves are pinned to the
-    reference's digest of phoebus.png by test_gpu_dropin.py::test_decode_png_resources_match_reference
-    (decode_png of a single file runs 8 wavefronts wide) and, for widths 1, 4 and the scan / LZ77
-    pair, by tests/test_emulator_kernels.py::test_p2_aliasing_replay_matches_reference_digest."""
+    """decode_png's buffer-aliasing replay (parameters p2_s0 / p2_est of debig_stream) is
+    part of every inflate kernel.  The reference's sample files (phoebus.png is the one whose last 756 bytes the
+    replay changes) go through inflate + de-filter with EVERY width and must come out with the REFERENCE's own
+    digest (tests/golden/resources.json, made by the compiled reference) -- not merely the same for all widths."""
+    import glob
+    import hashlib
+    import json
     import os
 
-    gold = os.path.join(os.path.dirname(__file__), "golden", "resources")
-    streams = {}
-    for name in sorted(os.listdir(gold)):
-        if not name.endswith(".png"):
-            continue
-        data = open(os.path.join(gold, name), "rb").read()
-        w = int.from_bytes(data[16:20], "big")
-        h = int.from_bytes(data[20:24], "big")
-        at, z = 8, b""
-        while at + 8 <= len(data):
-            ln = int.from_bytes(data[at:at + 4], "big")
-            if data[at + 4:at + 8] == b"IDAT":
-                z += data[at + 8:at + 8 + ln]
-            at += 12 + ln
-        if len(z) < 16:
-            continue
-        est = 4 * w * h + h + 1
-        s0 = est - 772 + ((16 - (est & 15)) & 15)
-        streams[name] = (z[2:-4], est, s0)
-    assert len(streams) >= 8
-    names = sorted(streams)
-    raws = [streams[n][0] for n in names]
-    caps = [max(streams[n][1], len(streams[n][0])) for n in names]
-    p2 = [(streams[n][2], streams[n][1]) for n in names]
-    b = DeviceBatch.from_streams(raws, caps, device=gpu_device, p2=p2)
-    got = {}
+    from debigulator_amd.png_device import DevicePngBatch
+
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    gold = json.load(open(os.path.join(gdir, "resources.json")))["png"]
+    files = [f for f in sorted(glob.glob(os.path.join(gdir, "resources", "*.png")))
+             if not f.endswith("backgrounddetailed1.png")]  # colour type 2: the P3 replay is another kernel's test
+    assert len(files) == 14 and any(f.endswith("phoebus.png") for f in files)
+    b = DevicePngBatch([open(f, "rb").read() for f in files], device=gpu_device)
     for width in WIDTHS:
-        b.d_out.zero_()
-        b.d_results.zero_()
+        b.inflate.d_out[:b.pal_base].fill_(0xA5)  # (the palettes live behind the streams)
+        b.inflate.d_results.zero_()
+        b.d_rgba.zero_()
         b.launch(waves_per_stream=width)
-        res = b.results()
-        got[width] = [(int(res[i]["good"]), int(res[i]["final_size"]), b.output(i, res)) for i in range(len(names))]
-    assert any(g for g, _, _ in got[1])
-    for width in WIDTHS[1:]:
-        for i, n in enumerate(names):
-            assert got[width][i] == got[1][i], (width, n)
+        res, ires = b.results()
+        assert (res["good"] == 1).all() and (ires["good"] == 1).all(), width
+        for k, f in enumerate(files):
+            name = os.path.basename(f)
+            assert hashlib.sha256(b.rgba(k).tobytes()).hexdigest() == gold[name]["rgba_sha256"], (hex(width), name)
 
 
 def test_chunked_path_against_the_oracle(oracle, gpu_device):

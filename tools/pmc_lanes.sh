@@ -2,7 +2,18 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 K=${1:-fixed}
-rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_INSTS_CBRANCH_TAKEN --output-format csv -d $R/gpurun_out/pmc_lanes_$K -- python3 $R/tools/bench_variant.py $K 4096 > $R/gpurun_out/pmc_lanes_$K.log 2>&1
+# one --pmc pass: at most 8 SQ counters (more abort in rocprofiler_create_counter_config: "Request exceeds the
+# capabilities of the hardware to collect", gpurun_out/r3w/pmc_c.log of round 3)
+pmc_pass() {
+    local out=$1; shift
+    local n=0 a
+    for a in "$@"; do [ "$a" = "--" ] && break; n=$((n + 1)); done
+    if [ $n -gt 8 ]; then echo "pmc_pass: $n counters in one pass (limit 8)" >&2; exit 2; fi
+    local counters=("${@:1:$n}"); shift $((n + 1))
+    rocprofv3 --kernel-trace --pmc "${counters[@]}" --output-format csv -d "$out" -- "$@"
+}
+
+pmc_pass $R/gpurun_out/pmc_lanes_$K SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_INSTS_CBRANCH_TAKEN -- python3 $R/tools/bench_variant.py $K 4096 > $R/gpurun_out/pmc_lanes_$K.log 2>&1
 cd $R
 python3 - <<PY
 import csv, glob, os
