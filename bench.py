@@ -522,7 +522,8 @@ def main():
     if rank == 0:
         value = job_d * args.steps / dt_max / 1e9
         digest = kernel_sources_digest()
-        split = len(res) > 1024  # include/debig_hip.h: what the library picks from the batch size
+        split = len(res) > 768  # include/debig_hip.h: what the library picks from the batch size (a workspace path)
+        strand = split and len(res) <= 3072  # ... DEBIG_WAVES_STRAND up to 3072 streams, DEBIG_WAVES_SPLIT beyond
         if cfg4:
             # inflate reads C and writes the filtered rows S; the de-filter reads S and writes the pixels P
             s_bytes = pbatch.s_bytes
@@ -531,7 +532,8 @@ def main():
             rl = roof(c_bytes + 2 * s_bytes, d_bytes, step_ms, what, None)
             rl["decompressed_GBps"] = d_bytes / step_ms / 1e6
         else:
-            rl = roof(c_bytes, d_bytes, step_ms, SPLIT_WHAT if split else
+            rl = roof(c_bytes, d_bytes, step_ms, (SPLIT_WHAT.replace("debig_scanlz_kernel", "debig_strand_kernel") if strand
+                                                  else SPLIT_WHAT) if split else
                       "one step = one debig_inflate(_mw)_kernel launch, whole batch on rank 0",
                       (2 if len(res) <= 16384 else 3 * ((len(res) + 16383) // 16384)) if split else 1)
         if not cfg5 and not cfg4:
@@ -583,7 +585,7 @@ def main():
             assert (r["good"] == 1).all()
             name = "roofline_huffman" if kind == "fixed" else "roofline_stored"
             line[name] = roof(cb, db, ms, f"{kind} streams launched alone ({len(r)} x 64 KiB), same kernels",
-                              2 if len(r) > 1024 else 1)
+                              2 if len(r) > 768 else 1)
         if not cfg4 and not cfg5 and split and len(res) <= 16384:
             # (a) the timed steps run over a workspace carved ONCE (DeviceBatch: debig_hip_inflate_plan_ws before the
             # warm-up); a caller of debig_hip_inflate_batch(_ws) with fresh descriptors pays debig_split_plan_kernel
@@ -628,7 +630,7 @@ def main():
         dt5, ms5, jd5, jc5, res5 = timed_steps(torch, np, dist, coll_dev, b5, verify5, args.cfg5_steps, 1, c5, d5)
         if rank == 0:
             r5 = roof(c5, d5, ms5, SPLIT_WHAT + " (rank 0's shard; member payloads, CRC-32 checked outside the timed region)",
-                      (2 if len(res5) <= 16384 else 3 * ((len(res5) + 16383) // 16384)) if len(res5) > 1024 else 1)
+                      (2 if len(res5) <= 16384 else 3 * ((len(res5) + 16383) // 16384)) if len(res5) > 768 else 1)
             line["cfg5_strong"] = {
                 "value": jd5 * args.cfg5_steps / dt5 / 1e9,
                 "unit": "GB/s",

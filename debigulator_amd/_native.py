@@ -37,6 +37,7 @@ class DebigPngResult(C.Structure):
 WAVES_SPLIT = 0x10  # include/debig_hip.h: DEBIG_WAVES_SPLIT
 WAVES_SPLIT_QUEUED = 0x11  # DEBIG_WAVES_SPLIT_QUEUED: persistent workgroups + work queue
 WAVES_STRAND = 0x12  # DEBIG_WAVES_STRAND: the long-segment scan in front of the same LZ77 half
+STRAND_MIN_STREAMS, STRAND_MAX_STREAMS = 768, 3072  # DEBIG_STRAND_MIN_STREAMS / _MAX_STREAMS: what width 0 picks
 WAVES_CHUNKED = 0x20  # include/debig_hip.h: DEBIG_WAVES_CHUNKED
 
 _lib = None

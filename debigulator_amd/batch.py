@@ -64,14 +64,14 @@ WAVES_LARGE4_SMALL1 = 0x41  # DEBIG_WAVES_LARGE4_SMALL1
 
 def pick_waves(streams):
     """csrc/host/debig_ctx.h: debig_pick_waves, line for line.  0 = the library's own choice from the
-    batch size (8 / 4 / 2 wavefronts per stream up to 256 / 512 / 1024 streams, the scan + LZ77 pair
-    beyond), which is what the C rule returns in those cases."""
+    batch size (8 / 4 / 2 wavefronts per stream up to 256 / 512 / 768 streams, the long-segment scan up to 3072,
+    the scan + LZ77 pair beyond), which is what the C rule returns in those cases."""
     n = len(streams)
     lens = streams["in_len"].astype(np.int64)
     if n <= 1024:
         if n and int(lens.sum()) >= n << 20:  # few streams, >= 1 MiB of input each on average
             return N.WAVES_CHUNKED
-        return 0
+        return 0  # (8 / 4 / 2 wavefronts per stream up to 256 / 512 / 768 streams, WAVES_STRAND up to 1024)
     n_large = int(((lens >= LARGE_IN_BYTES) | (streams["out_cap"].astype(np.int64) >= LARGE_OUT_BYTES)).sum())
     if int(lens.max()) >= 4 << 20 and n <= 16384:  # thousands of streams, a very large one among them
         return N.WAVES_CHUNKED
@@ -140,11 +140,14 @@ class DeviceBatch:
         if waves_per_stream == N.WAVES_CHUNKED:
             return self._launch_chunked(stream)
         ws_ptr, ws_bytes = None, 0
-        if waves_per_stream in (N.WAVES_SPLIT, N.WAVES_SPLIT_QUEUED, N.WAVES_STRAND) or (waves_per_stream == 0 and self.n > 1024 and
-                                                                         not os.environ.get("DEBIG_WAVES_PER_STREAM")):
+        if waves_per_stream == 0 and self.n > N.STRAND_MIN_STREAMS and not os.environ.get("DEBIG_WAVES_PER_STREAM"):
+            # include/debig_hip.h: what 0 means for this many streams
+            waves_per_stream = N.WAVES_STRAND if self.n <= N.STRAND_MAX_STREAMS else N.WAVES_SPLIT
+        if waves_per_stream in (N.WAVES_SPLIT, N.WAVES_SPLIT_QUEUED, N.WAVES_STRAND):
             if self.d_ws is None:  # caller-owned workspace: nothing is allocated inside the call
                 total_in = int(self.streams_host["in_len"].sum())
                 nbytes = int(self.lib.debig_hip_inflate_workspace_bytes(total_in, self.n))
+                nbytes = int(nbytes * float(os.environ.get("DEBIG_WS_SCALE", "1")))  # experiments: a larger / smaller token workspace
                 self.d_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             ws_ptr, ws_bytes = self.d_ws.data_ptr(), self.d_ws.numel()
             if self.n <= 16384:
@@ -160,7 +163,7 @@ class DeviceBatch:
                 if self._planned:
                     N.check(self.lib.debig_hip_inflate_planned_ws_ex(self.d_in.data_ptr(), self.d_out.data_ptr(),
                                                                      self.d_streams.data_ptr(), self.d_results.data_ptr(), self.n,
-                                                                     waves_per_stream or N.WAVES_SPLIT,
+                                                                     waves_per_stream,
                                                                      ws_ptr, ws_bytes, C.c_void_p(stream.cuda_stream)),
                             "debig_hip_inflate_planned_ws_ex")
                     return

@@ -125,7 +125,13 @@ static uint32_t auto_waves_per_stream(uint32_t n)
     if (env_val) return env_val;
     if (n <= 256u) return 8u;
     if (n <= 512u) return 4u;
-    if (n <= 1024u) return 2u;
+    if (n <= DEBIG_STRAND_MIN_STREAMS) return 2u;
+    // 769..3072 streams: fewer wavefronts than the chip holds (under 3 per SIMD): every wavefront is bound by its
+    // own chain of dependent look-ups, and the long-segment scan decodes every symbol once (profiles/r04_width_grid.txt:
+    // 1024 streams of 64 KiB / 1 MiB: 2-wide 36 / 36, pair 62 / 63, strands 66 / 80 GB/s on image rows; 2048 streams:
+    // pair 110 / 109, strands 116 / 133).  Beyond that the chip is full, both paths are bound by their VALU
+    // instructions and the 68-byte scan's shorter tail wins by 3..12 %.
+    if (n <= DEBIG_STRAND_MAX_STREAMS) return DEBIG_WAVES_STRAND;
     return DEBIG_WAVES_SPLIT;
 }
 
@@ -358,10 +364,14 @@ static SideLane *side_lane(hipStream_t s)
 uint64_t debig_hip_inflate_workspace_bytes(uint64_t total_in_bytes, uint32_t n)
 {
     // token rows: about 4-5 x the compressed bytes for text-like data (one 256-byte row per symbol
-    // index of a 64-lane window) + per-stream slack for partial windows; records and slots on top
+    // index of a 64-lane window) + per-stream slack for partial windows; records and slots on top.
+    // 12 x since round 4 (was 9): the long-segment scan (DEBIG_WAVES_STRAND) stores a 64-byte unit per lane and
+    // phase until its slowest lane is done, and literal-heavy data with short codes (noisy image rows: 1.4
+    // symbols per compressed byte) needed 10-11 x -- with 9 x a quarter of such streams went to the one-kernel
+    // path (4096 x 64 KiB: 3.2 ms instead of 1.7)
     const uint32_t group = n < SPLIT_GROUP ? n : SPLIT_GROUP;
     const uint64_t per_group_in = n ? (total_in_bytes + n - 1) / n * group : 0; /* average streams */
-    return align_up((uint64_t)group * (sizeof(debig_ws_slot) + 24576u) + per_group_in * 9u, 4096);
+    return align_up((uint64_t)group * (sizeof(debig_ws_slot) + 24576u) + per_group_in * 12u, 4096);
 }
 
 uint64_t debig_hip_inflate_chunked_workspace_bytes(uint64_t total_in_bytes, uint64_t total_out_bytes, uint32_t n)

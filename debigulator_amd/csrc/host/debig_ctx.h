@@ -67,7 +67,8 @@ static inline uint32_t debig_pick_waves(const debig_stream *desc, uint32_t n)
     }
     if (n <= 256u) return 8u;
     if (n <= 512u) return 4u;
-    if (n <= 1024u) return 2u;
+    if (n <= DEBIG_STRAND_MIN_STREAMS) return 2u;
+    if (n <= 1024u) return DEBIG_WAVES_STRAND; /* (debig_hip.hip: auto_waves_per_stream has the measurements) */
     uint32_t n_large = 0;
     uint64_t longest = 0;
     for (uint32_t i = 0; i < n; i++) {
@@ -77,7 +78,8 @@ static inline uint32_t debig_pick_waves(const debig_stream *desc, uint32_t n)
     /* thousands of streams and a very large one among them: chunk tasks for everything (a small
      * stream is one task: the scan / LZ77 bodies of the throughput path) */
     if (longest >= DEBIG_CHUNKED_LONGEST_IN_BYTES && n <= 16384u) return DEBIG_WAVES_CHUNKED;
-    return (n_large != 0 && n_large <= 256u) ? DEBIG_WAVES_LARGE4_SMALL1 : DEBIG_WAVES_SPLIT;
+    if (n_large != 0 && n_large <= 256u) return DEBIG_WAVES_LARGE4_SMALL1;
+    return n <= DEBIG_STRAND_MAX_STREAMS ? DEBIG_WAVES_STRAND : DEBIG_WAVES_SPLIT;
 }
 
 /* Dispatch plan for one inflate launch.  Workgroups start in descriptor order, so for a batch

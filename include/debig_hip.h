@@ -103,8 +103,9 @@ int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d
  *              by stream: large ones (>= 256 KiB of input or >= 1 MiB of recipient) 4-wide,
  *              the others 1- or 2-wide, as two launches that run side by side (an internal
  *              HIP stream; hip_stream continues only after both)
- *   0          the library picks from n: n <= 256: 8; n <= 512: 4; n <= 1024: 2; else 1 (never a mixed
- *              mode: stream sizes are in device memory).  debig_hip_inflate_batch does this.
+ *   0          the library picks from n: n <= 256: 8; n <= 512: 4; n <= 768: 2; n <= 3072: DEBIG_WAVES_STRAND;
+ *              else DEBIG_WAVES_SPLIT (never a mixed mode: stream sizes are in device memory).
+ *              debig_hip_inflate_batch does this.
  *              The environment variable DEBIG_WAVES_PER_STREAM (1, 2, 4, 0x41, 0x42)
  *              replaces this choice, for measurements.
  * Results are identical for every choice.  Any other value: hipErrorInvalidValue. */
@@ -145,6 +146,8 @@ int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d
  *              pass, and only the lanes whose guessed start was wrong are decoded again, up to the point
  *              where they rejoin their first decode.  Same workspace, same results. */
 #define DEBIG_WAVES_STRAND 0x12u
+#define DEBIG_STRAND_MIN_STREAMS 768u  /* what 0 picks: up to here 2 wavefronts per stream ...            */
+#define DEBIG_STRAND_MAX_STREAMS 3072u /* ... DEBIG_WAVES_STRAND up to here, DEBIG_WAVES_SPLIT beyond      */
 /*   DEBIG_WAVES_CHUNKED
  *              a FEW LARGE streams (hundreds of big PNG images): every stream is cut at DEFLATE
  *              block boundaries into chunk tasks of 32..256 KiB of input, found by looking for
@@ -175,7 +178,7 @@ int debig_hip_init(void *hip_stream);
  * Same with caller-owned workspace for DEBIG_WAVES_SPLIT (no allocation inside the call once
  * debig_hip_init() has run on the device: safe to capture into a hipGraph).
  * debig_hip_inflate_workspace_bytes() is the size that lets ordinary
- * data through the scan/LZ77 pair (about 9 x the compressed bytes of the largest group of 16384
+ * data through the scan/LZ77 pair (about 12 x the compressed bytes of the largest group of 16384
  * streams + 24 KiB per stream); less is legal and only sends more streams down the one-kernel
  * path.  d_workspace = NULL: the internal cached workspace.  The workspace holds no state between
  * calls. */
