@@ -77,8 +77,8 @@ def parse_args():
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed even at N = 1")
     ap.add_argument("--no-cfg5", action="store_true", help="cfg2: skip the cfg5_strong record")
-    ap.add_argument("--no-kinds", action="store_true", help="cfg2: skip roofline_huffman / roofline_stored (profiling "
-                    "runs: the kernel statistics then hold whole-batch launches only)")
+    ap.add_argument("--no-kinds", action="store_true", help="cfg2: skip roofline_huffman / roofline_stored / ms_with_plan / roofline_interleaved "
+                    "(profiling runs: the kernel statistics then hold whole-batch launches only)")
     ap.add_argument("--cfg5-steps", type=int, default=3, help="timed steps of the cfg5_strong record")
     args = ap.parse_args()
     if args.steps is None:
@@ -586,7 +586,7 @@ def main():
             name = "roofline_huffman" if kind == "fixed" else "roofline_stored"
             line[name] = roof(cb, db, ms, f"{kind} streams launched alone ({len(r)} x 64 KiB), same kernels",
                               2 if len(r) > 768 else 1)
-        if not cfg4 and not cfg5 and split and len(res) <= 16384:
+        if not cfg4 and not cfg5 and split and len(res) <= 16384 and not args.no_kinds:
             # (a) the timed steps run over a workspace carved ONCE (DeviceBatch: debig_hip_inflate_plan_ws before the
             # warm-up); a caller of debig_hip_inflate_batch(_ws) with fresh descriptors pays debig_split_plan_kernel
             # on every call: the same step with the plan kernel in it

@@ -233,7 +233,7 @@ static int launch_split_group(hipStream_t s, const void *d_in, void *d_out, cons
                               debig_result *d_results, uint32_t n, const FixedTabs *tabs, void *ws, uint64_t ws_bytes,
                               int what = 3, int queued = 0)
 {
-    const uint64_t slots_bytes = align_up((uint64_t)n * sizeof(debig_ws_slot) + 4u * SPLIT_QUEUE_WORDS, 256); /* + the work queue */
+    const uint64_t slots_bytes = align_up((uint64_t)n * sizeof(debig_ws_slot) + 4u * SPLIT_QUEUE_WORDS + 4u * (uint64_t)n, 256); /* + the work queue + the dispatch order */
     if (ws_bytes < slots_bytes + (uint64_t)n * 1024u) return -1;
     const uint64_t rest = ws_bytes - slots_bytes;
     const uint64_t total_recs = rest / 16u / sizeof(debig_ws_rec);

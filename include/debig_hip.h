@@ -123,11 +123,14 @@ int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d
  *              (debig_hip_inflate_batch_ws; debig_hip_inflate_batch / _ex use a cached internal
  *              one of DEBIG_WORKSPACE_MB MiB, default 1024); a stream that does not fit its share
  *              is decoded by the one-kernel path in the same call.
- *              ORDER MATTERS: one workgroup per stream is dealt to the shader engines by index, whatever it
- *              costs.  A batch sorted or grouped by kind / size (all Huffman streams, then all stored ones: what
- *              bench.py times) is the good case; the same streams alternating kinds run up to 1.8 x slower
- *              (bench.py reports both: roofline and roofline_interleaved).  Callers that cannot group their
- *              descriptors use DEBIG_WAVES_SPLIT_QUEUED. */
+ *              ORDER: one workgroup per stream is dealt to the shader engines by index, whatever it costs,
+ *              so since round 4 the plan step also fixes the DISPATCH order: streams that look expensive
+ *              (recipient larger than input + 64 bytes) first, stored / incompressible ones behind them, each
+ *              class in the caller's order.  Stored and Huffman streams alternating in the descriptors
+ *              (1.59 ms before, 1.8 x the sorted batch) now take what the sorted batch takes (0.91 vs 0.89 ms:
+ *              bench.py reports both, roofline and roofline_interleaved).  What is left to the caller: batches
+ *              whose expensive streams differ a lot among themselves (thumbnails beside full images): group
+ *              them by size, or use DEBIG_WAVES_SPLIT_QUEUED. */
 #define DEBIG_WAVES_SPLIT 0x10u
 /*   DEBIG_WAVES_SPLIT_QUEUED
  *              DEBIG_WAVES_SPLIT for a batch whose ORDER mixes cheap and expensive streams (stored and

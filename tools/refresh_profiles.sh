@@ -27,8 +27,12 @@ for f in glob.glob("$O/fetch_cal/**/*counter_collection.csv", recursive=True):
 PY
 echo "[refresh] counters and phases"
 bash tools/pmc_split.sh fixed > $O/pmc_split_fixed.txt 2>&1 || true
-python3 tools/prof_split.py fixed > $O/phases_split_fixed.txt 2>&1 || true
-python3 tools/prof_split.py dynamic > $O/phases_split_dynamic.txt 2>&1 || true
+python3 tools/prof_split.py fixed 4096 65536 0x10 > $O/phases_split_fixed.txt 2>&1 || true
+python3 tools/prof_split.py dynamic 4096 65536 0x10 > $O/phases_split_dynamic.txt 2>&1 || true
 echo "[refresh] bench line"
 python3 bench.py > $O/bench_line.json 2> $O/bench_stderr.log
 tail -1 $O/bench_line.json | cut -c1-400
+echo "[refresh] the long-segment scan (DEBIG_WAVES_STRAND): counters, phases"
+bash tools/pmc_width.sh fixed 0x12 debig_strand_kernel > $O/pmc_strand_fixed.txt 2>&1 || true
+python3 tools/prof_split.py fixed 4096 65536 0x12 > $O/phases_strand_fixed.txt 2>&1 || true
+python3 tools/prof_split.py dynamic 2048 1048576 0x12 > $O/phases_strand_dynamic_1m.txt 2>&1 || true

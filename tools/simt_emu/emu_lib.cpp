@@ -81,7 +81,7 @@ extern "C" int emu_inflate_split_batch(const void *in, void *out, const debig_st
         fts = (uint32_t *)calloc(1, sizeof(decltype(ScanLds::t)));
         EMU_LAUNCH(debig_scan_fixed_tables_kernel, 1, 64, fts);
     }
-    const uint64_t slots_bytes = ((uint64_t)n * sizeof(debig_ws_slot) + 4u * SPLIT_QUEUE_WORDS + 255) / 256 * 256;
+    const uint64_t slots_bytes = ((uint64_t)n * sizeof(debig_ws_slot) + 4u * SPLIT_QUEUE_WORDS + 4u * (uint64_t)n + 255) / 256 * 256;
     if (ws_bytes < slots_bytes + (uint64_t)n * 1024u) return -1;
     uint8_t *ws = (uint8_t *)malloc(ws_bytes);
     memset(ws, 0xEE, ws_bytes); /* poison: nothing may be read before it is written */
@@ -93,6 +93,20 @@ extern "C" int emu_inflate_split_batch(const void *in, void *out, const debig_st
     debig_ws_rec *recs = (debig_ws_rec *)(ws + slots_bytes);
     uint32_t *rows = (uint32_t *)(ws + slots_bytes + recs_bytes);
     EMU_LAUNCH(debig_split_plan_kernel, 1, EMU_PLAN_THREADS, streams, n, slots, total_rows, total_recs);
+    { /* the dispatch order must be a permutation: streams that look expensive first, each class in the caller's order */
+        const uint32_t *perm = split_perm(slots, n);
+        std::vector<uint8_t> seen(n, 0);
+        int in_cheap = 0;
+        uint32_t last_e = 0, last_c = 0;
+        for (uint32_t b = 0; b < n; b++) {
+            const uint32_t i = perm[b];
+            if (i >= n || seen[i]) return -3;
+            seen[i] = 1;
+            const int cheap = split_stream_is_cheap(streams[i]);
+            if (cheap) { if (in_cheap && i < last_c) return -3; in_cheap = 1; last_c = i; }
+            else { if (in_cheap || (b && i < last_e)) return -3; last_e = i; }
+        }
+    }
     if (getenv("DEBIG_EMU_TWO_KERNELS")) { /* the two halves as separate kernels (the chunk path's shape) */
         EMU_LAUNCH(debig_scan_kernel, n, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
         EMU_LAUNCH(debig_lz_kernel, n, 64, (uint8_t *)out, streams, results, n, (const debig_ws_slot *)slots,
