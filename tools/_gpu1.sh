@@ -1,9 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python bench.py --no-cfg5 --no-cpu-baseline > gpurun_out/r4b/bench_perm.json 2>/dev/null
-python -c "
-import json; l=json.load(open('gpurun_out/r4b/bench_perm.json')); r=l['roofline']
-print('value', l['value'], 'ms', l['ms_per_step'], 'frac', r['frac'], 'with_plan', r.get('ms_with_plan'))
-print('huff', l['roofline_huffman']['decompressed_GBps'], 'stored', l['roofline_stored']['frac'], 'interleaved ms', l['roofline_interleaved']['avg_step_ms'], l['roofline_interleaved']['frac'])
-"
-python tools/bench_mixed_order.py 2>&1 | grep -v amdgpu.ids | tail -12
+for k in fixed dynamic png; do for w in 0x10 0x12; do python tools/bench_variant.py $k 4096 $w 65536 2>&1 | tail -1; done; done
+for k in fixed png; do for w in 0x10 0x12; do python tools/bench_variant.py $k 2048 $w 65536 2>&1 | tail -1; done; done
+for w in 0x10 0x12; do python tools/bench_variant.py dynamic 2048 $w 1048576 2>&1 | tail -1; done
+for w in 0x10 0x12; do python tools/bench_gz.py 8192 1048576 $w 2>&1 | grep "inflate  "; done
