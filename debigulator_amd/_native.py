@@ -37,6 +37,8 @@ class DebigPngResult(C.Structure):
 WAVES_SPLIT = 0x10  # include/debig_hip.h: DEBIG_WAVES_SPLIT
 WAVES_SPLIT_QUEUED = 0x11  # DEBIG_WAVES_SPLIT_QUEUED: persistent workgroups + work queue
 WAVES_STRAND = 0x12  # DEBIG_WAVES_STRAND: the long-segment scan in front of the same LZ77 half
+WAVES_STRAND_PIPE = 0x13  # DEBIG_WAVES_STRAND_PIPE: scan and LZ77 wavefronts side by side in one workgroup
+STRAND_PIPE_MAX_STREAMS, STRAND_PIPE_MEAN_IN_BYTES = 2048, 128 << 10  # DEBIG_STRAND_PIPE_MAX_STREAMS / _MEAN_IN_BYTES
 STRAND_MIN_STREAMS, STRAND_MAX_STREAMS = 768, 3072  # DEBIG_STRAND_MIN_STREAMS / _MAX_STREAMS: what width 0 picks
 WAVES_CHUNKED = 0x20  # include/debig_hip.h: DEBIG_WAVES_CHUNKED
 

@@ -71,7 +71,9 @@ def pick_waves(streams):
     if n <= 1024:
         if n and int(lens.sum()) >= n << 20:  # few streams, >= 1 MiB of input each on average
             return N.WAVES_CHUNKED
-        return 0  # (8 / 4 / 2 wavefronts per stream up to 256 / 512 / 768 streams, WAVES_STRAND up to 1024)
+        if 256 < n <= N.STRAND_MIN_STREAMS and int(lens.sum()) >= n * N.STRAND_PIPE_MEAN_IN_BYTES:
+            return N.WAVES_STRAND_PIPE  # long streams: scan and LZ77 half side by side
+        return 0  # (8 / 4 / 2 wavefronts per stream up to 256 / 512 / 768 streams, the pipeline up to 1024)
     n_large = int(((lens >= LARGE_IN_BYTES) | (streams["out_cap"].astype(np.int64) >= LARGE_OUT_BYTES)).sum())
     if int(lens.max()) >= 4 << 20 and n <= 16384:  # thousands of streams, a very large one among them
         return N.WAVES_CHUNKED
@@ -142,8 +144,9 @@ class DeviceBatch:
         ws_ptr, ws_bytes = None, 0
         if waves_per_stream == 0 and self.n > N.STRAND_MIN_STREAMS and not os.environ.get("DEBIG_WAVES_PER_STREAM"):
             # include/debig_hip.h: what 0 means for this many streams
-            waves_per_stream = N.WAVES_STRAND if self.n <= N.STRAND_MAX_STREAMS else N.WAVES_SPLIT
-        if waves_per_stream in (N.WAVES_SPLIT, N.WAVES_SPLIT_QUEUED, N.WAVES_STRAND):
+            waves_per_stream = (N.WAVES_STRAND_PIPE if self.n <= N.STRAND_PIPE_MAX_STREAMS else
+                                N.WAVES_STRAND if self.n <= N.STRAND_MAX_STREAMS else N.WAVES_SPLIT)
+        if waves_per_stream in (N.WAVES_SPLIT, N.WAVES_SPLIT_QUEUED, N.WAVES_STRAND, N.WAVES_STRAND_PIPE):
             if self.d_ws is None:  # caller-owned workspace: nothing is allocated inside the call
                 total_in = int(self.streams_host["in_len"].sum())
                 nbytes = int(self.lib.debig_hip_inflate_workspace_bytes(total_in, self.n))

@@ -131,6 +131,10 @@ static uint32_t auto_waves_per_stream(uint32_t n)
     // 1024 streams of 64 KiB / 1 MiB: 2-wide 36 / 36, pair 62 / 63, strands 66 / 80 GB/s on image rows; 2048 streams:
     // pair 110 / 109, strands 116 / 133).  Beyond that the chip is full, both paths are bound by their VALU
     // instructions and the 68-byte scan's shorter tail wins by 3..12 %.
+    // up to 2048 streams a second wavefront per stream still finds an empty slot: scan and LZ77 half side by side
+    // (debig_strand_pipe_kernel; 1024 x 1 MiB text 166 -> 244 GB/s, 2048: 277 -> 351, 3072: 348 -> 308;
+    // single-window streams -- 64 KiB -- have nothing to overlap and run as fast either way)
+    if (n <= DEBIG_STRAND_PIPE_MAX_STREAMS) return DEBIG_WAVES_STRAND_PIPE;
     if (n <= DEBIG_STRAND_MAX_STREAMS) return DEBIG_WAVES_STRAND;
     return DEBIG_WAVES_SPLIT;
 }
@@ -250,7 +254,10 @@ static int launch_split_group(hipStream_t s, const void *d_in, void *d_out, cons
 #endif
 #if DEBIG_SPLIT_FUSED
     const uint32_t cap = queued == 1 ? scanlz_resident_workgroups() : 0u;
-    if (queued == 2) /* DEBIG_WAVES_STRAND: the long-segment scan in front of the same LZ77 half */
+    if (queued == 3) /* DEBIG_WAVES_STRAND_PIPE: the same two halves on two wavefronts of a workgroup, record by record */
+        hipLaunchKernelGGL(debig_strand_pipe_kernel, dim3(n), dim3(128), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, n,
+                           tabs->scan, slots, recs, rows, d_results);
+    else if (queued == 2) /* DEBIG_WAVES_STRAND: the long-segment scan in front of the same LZ77 half */
         hipLaunchKernelGGL(debig_strand_kernel, dim3(n), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, n,
                            tabs->scan, slots, recs, rows, d_results);
     else if (queued && n > cap) /* persistent workgroups: as many as the device holds at once, streams from a queue */
@@ -393,7 +400,8 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
     const int mixed = waves_per_stream == DEBIG_WAVES_LARGE4_SMALL1 || waves_per_stream == DEBIG_WAVES_LARGE4_SMALL2;
     if (!mixed && waves_per_stream != 1 && waves_per_stream != 2 && waves_per_stream != 4 && waves_per_stream != 8 &&
         waves_per_stream != DEBIG_WAVES_SPLIT && waves_per_stream != DEBIG_WAVES_SPLIT_QUEUED &&
-        waves_per_stream != DEBIG_WAVES_STRAND && waves_per_stream != DEBIG_WAVES_CHUNKED)
+        waves_per_stream != DEBIG_WAVES_STRAND && waves_per_stream != DEBIG_WAVES_STRAND_PIPE &&
+        waves_per_stream != DEBIG_WAVES_CHUNKED)
         return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)hip_stream;
     const FixedTabs *ft = fixed_tables(s);
@@ -417,7 +425,7 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
         waves_per_stream = n <= 256u ? 8u : n <= 512u ? 4u : n <= 1024u ? 2u : 1u; /* no usable workspace */
     }
     if (waves_per_stream == DEBIG_WAVES_SPLIT || waves_per_stream == DEBIG_WAVES_SPLIT_QUEUED ||
-        waves_per_stream == DEBIG_WAVES_STRAND) {
+        waves_per_stream == DEBIG_WAVES_STRAND || waves_per_stream == DEBIG_WAVES_STRAND_PIPE) {
         DefaultWs *shared = nullptr;
         if (!d_workspace) {
             shared = default_workspace(s);
@@ -428,7 +436,8 @@ int debig_hip_inflate_batch_ws(const void *d_in, void *d_out, const debig_stream
             SharedWsUse hold(shared, s);
             if (hold.err) return hold.err;
             rc = launch_split(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes,
-                              waves_per_stream == DEBIG_WAVES_SPLIT_QUEUED ? 1 : waves_per_stream == DEBIG_WAVES_STRAND ? 2 : 0);
+                              waves_per_stream == DEBIG_WAVES_SPLIT_QUEUED ? 1 : waves_per_stream == DEBIG_WAVES_STRAND ? 2 :
+                              waves_per_stream == DEBIG_WAVES_STRAND_PIPE ? 3 : 0);
             const int frc = hold.finish();
             if (rc == 0 && frc) return frc;
         }
@@ -473,14 +482,15 @@ int debig_hip_inflate_planned_ws_ex(const void *d_in, void *d_out, const debig_s
     if (n == 0) return 0;
     if (n > SPLIT_GROUP || !d_workspace) return (int)hipErrorInvalidValue;
     if (waves_per_stream != DEBIG_WAVES_SPLIT && waves_per_stream != DEBIG_WAVES_SPLIT_QUEUED &&
-        waves_per_stream != DEBIG_WAVES_STRAND)
+        waves_per_stream != DEBIG_WAVES_STRAND && waves_per_stream != DEBIG_WAVES_STRAND_PIPE)
         return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)hip_stream;
     DeviceGuard launch_guard(launch_device(s));
     const FixedTabs *ft = fixed_tables(s);
     if (!ft) return (int)hipErrorOutOfMemory;
     int rc = launch_split_group(s, d_in, d_out, d_streams, d_results, n, ft, d_workspace, workspace_bytes, 2,
-                                waves_per_stream == DEBIG_WAVES_SPLIT_QUEUED ? 1 : waves_per_stream == DEBIG_WAVES_STRAND ? 2 : 0);
+                                waves_per_stream == DEBIG_WAVES_SPLIT_QUEUED ? 1 : waves_per_stream == DEBIG_WAVES_STRAND ? 2 :
+                              waves_per_stream == DEBIG_WAVES_STRAND_PIPE ? 3 : 0);
     return rc < 0 ? (int)hipErrorInvalidValue : rc;
 }
 

@@ -291,7 +291,7 @@ int debig_launch_inflate_planned(debig_ctx *c, const void *d_in_arena, const deb
     }
     const uint32_t w = permuted ? waves : debig_pick_waves(desc, n);
     uint64_t ws_bytes = 0;
-    if (w == DEBIG_WAVES_SPLIT || w == DEBIG_WAVES_STRAND) { /* the throughput paths want a token workspace sized from the input */
+    if (w == DEBIG_WAVES_SPLIT || w == DEBIG_WAVES_STRAND || w == DEBIG_WAVES_STRAND_PIPE) { /* the throughput paths want a token workspace sized from the input */
         uint64_t total_in = 0;
         for (uint32_t i = 0; i < n; i++) total_in += desc[i].in_len;
         ws_bytes = debig_hip_inflate_workspace_bytes(total_in, n);

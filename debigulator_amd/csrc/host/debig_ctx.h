@@ -66,9 +66,16 @@ static inline uint32_t debig_pick_waves(const debig_stream *desc, uint32_t n)
         if (total_in >= (uint64_t)n * DEBIG_CHUNKED_MEAN_IN_BYTES) return DEBIG_WAVES_CHUNKED;
     }
     if (n <= 256u) return 8u;
-    if (n <= 512u) return 4u;
-    if (n <= DEBIG_STRAND_MIN_STREAMS) return 2u;
-    if (n <= 1024u) return DEBIG_WAVES_STRAND; /* (debig_hip.hip: auto_waves_per_stream has the measurements) */
+    if (n <= DEBIG_STRAND_MIN_STREAMS) {
+        /* long streams (several windows each): scan and LZ77 half side by side beat a workgroup per stream
+         * (profiles/r04_pipe.txt: 384 x 1 MiB image rows 37 -> 49 GB/s, 512 x 1 MiB text 112 -> 132; 512 x 64 KiB:
+         * 86 4-wide, 65 as a pipeline -- one window per stream, nothing to overlap) */
+        uint64_t total_in = 0;
+        for (uint32_t i = 0; i < n; i++) total_in += desc[i].in_len;
+        if (total_in >= (uint64_t)n * DEBIG_STRAND_PIPE_MEAN_IN_BYTES) return DEBIG_WAVES_STRAND_PIPE;
+        return n <= 512u ? 4u : 2u;
+    }
+    if (n <= 1024u) return DEBIG_WAVES_STRAND_PIPE; /* (debig_hip.hip: auto_waves_per_stream has the measurements) */
     uint32_t n_large = 0;
     uint64_t longest = 0;
     for (uint32_t i = 0; i < n; i++) {
@@ -79,6 +86,7 @@ static inline uint32_t debig_pick_waves(const debig_stream *desc, uint32_t n)
      * stream is one task: the scan / LZ77 bodies of the throughput path) */
     if (longest >= DEBIG_CHUNKED_LONGEST_IN_BYTES && n <= 16384u) return DEBIG_WAVES_CHUNKED;
     if (n_large != 0 && n_large <= 256u) return DEBIG_WAVES_LARGE4_SMALL1;
+    if (n <= DEBIG_STRAND_PIPE_MAX_STREAMS) return DEBIG_WAVES_STRAND_PIPE;
     return n <= DEBIG_STRAND_MAX_STREAMS ? DEBIG_WAVES_STRAND : DEBIG_WAVES_SPLIT;
 }
 

@@ -103,8 +103,10 @@ int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d
  *              by stream: large ones (>= 256 KiB of input or >= 1 MiB of recipient) 4-wide,
  *              the others 1- or 2-wide, as two launches that run side by side (an internal
  *              HIP stream; hip_stream continues only after both)
- *   0          the library picks from n: n <= 256: 8; n <= 512: 4; n <= 768: 2; n <= 3072: DEBIG_WAVES_STRAND;
- *              else DEBIG_WAVES_SPLIT (never a mixed mode: stream sizes are in device memory).
+ *   0          the library picks from n: n <= 256: 8; n <= 512: 4; n <= 768: 2; n <= 2048: DEBIG_WAVES_STRAND_PIPE;
+ *              n <= 3072: DEBIG_WAVES_STRAND; else DEBIG_WAVES_SPLIT (never a mixed mode: stream sizes are in
+ *              device memory; the host batch calls, which see the sizes, also take the pipeline for 257..768
+ *              streams of 128 KiB of input or more on average).
  *              debig_hip_inflate_batch does this.
  *              The environment variable DEBIG_WAVES_PER_STREAM (1, 2, 4, 0x41, 0x42)
  *              replaces this choice, for measurements.
@@ -149,8 +151,16 @@ int debig_hip_inflate_batch(const void *d_in, void *d_out, const debig_stream *d
  *              pass, and only the lanes whose guessed start was wrong are decoded again, up to the point
  *              where they rejoin their first decode.  Same workspace, same results. */
 #define DEBIG_WAVES_STRAND 0x12u
+/*   DEBIG_WAVES_STRAND_PIPE
+ *              DEBIG_WAVES_STRAND as a pipeline inside a workgroup of TWO wavefronts: one scans the stream, the other
+ *              replays what the first has finished, record by record (a window, a stored block).  For batches that
+ *              leave most SIMDs one or two wavefronts (a few hundred to about two thousand streams): a stream then
+ *              takes max(scan, LZ77) instead of their sum.  Same workspace, same results. */
+#define DEBIG_WAVES_STRAND_PIPE 0x13u
 #define DEBIG_STRAND_MIN_STREAMS 768u  /* what 0 picks: up to here 2 wavefronts per stream ...            */
 #define DEBIG_STRAND_MAX_STREAMS 3072u /* ... DEBIG_WAVES_STRAND up to here, DEBIG_WAVES_SPLIT beyond      */
+#define DEBIG_STRAND_PIPE_MAX_STREAMS 2048u /* ... and up to here as a two-wavefront pipeline (DEBIG_WAVES_STRAND_PIPE) */
+#define DEBIG_STRAND_PIPE_MEAN_IN_BYTES (128u << 10) /* host batch calls: 257..768 streams this long on average also take it */
 /*   DEBIG_WAVES_CHUNKED
  *              a FEW LARGE streams (hundreds of big PNG images): every stream is cut at DEFLATE
  *              block boundaries into chunk tasks of 32..256 KiB of input, found by looking for

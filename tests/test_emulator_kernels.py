@@ -26,10 +26,10 @@ def emu():
 
 
 # wavefronts per stream: 1 = debig_inflate_kernel, 2 / 4 = debig_inflate_mw_kernel<NW>
-@pytest.mark.parametrize("nw", [1, 2, 4, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND])
+@pytest.mark.parametrize("nw", [1, 2, 4, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND, eb.STRAND_PIPE])
 def test_known_answers_and_corpus(emu, nw):
     items = json.load(open(os.path.join(GOLD, "kat.json")))
-    items += json.load(open(os.path.join(GOLD, "corpus_zlib.json")))[:80 if nw in (1, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND) else 40]
+    items += json.load(open(os.path.join(GOLD, "corpus_zlib.json")))[:80 if nw in (1, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND, eb.STRAND_PIPE) else 40]
     raws = [bytes.fromhex(k["raw_hex"]) for k in items]
     caps = [k["recipient_size"] for k in items]
     outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, in_misalign=3, out_misalign=5)
@@ -44,10 +44,10 @@ def test_known_answers_and_corpus(emu, nw):
         assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
 
 
-@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND, eb.STRAND_PIPE])
 def test_corrupt_corpus_reference_made(emu, nw):
     """tests/golden/corpus_corrupt.json: damaged streams with the REFERENCE's own answers (build B)"""
-    items = json.load(open(os.path.join(GOLD, "corpus_corrupt.json")))[:: 1 if nw in (1, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND) else 3]
+    items = json.load(open(os.path.join(GOLD, "corpus_corrupt.json")))[:: 1 if nw in (1, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND, eb.STRAND_PIPE) else 3]
     raws = [bytes.fromhex(k["raw_hex"]) for k in items]
     caps = [k["recipient_size"] for k in items]
     outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, out_misalign=1)
@@ -104,7 +104,7 @@ def test_multi_wavefront_kernel_crosses_windows_and_tiles(emu):
     assert r.n_windows >= 2
 
 
-@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND, eb.STRAND_PIPE])
 def test_end_position_and_no_gates_flag(emu, nw):
     """debig_result.in_end_bits (where decoding stopped) and DEBIG_STREAM_NO_REF_GATES: what a
     container with several members needs (debig_gunzip_batch).  A raw stream followed by other
@@ -158,7 +158,7 @@ def _tiny_block_streams(seed, count, max_len):
     return raws, caps
 
 
-@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND, eb.STRAND_PIPE])
 def test_streams_of_tiny_blocks_take_the_probe_path(emu, oracle, nw):
     raws, caps = _tiny_block_streams(31 + nw, 12 if nw == 1 else 6, 1500)
     outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, in_misalign=5, out_misalign=11)
@@ -190,7 +190,7 @@ def test_mixed_width_launches_partition_the_batch(emu, oracle):
     assert [r.final_set for _, _, _, r in only_large] == [it % 2 for it in range(10)]
 
 
-@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND, eb.STRAND_PIPE])
 def test_corrupt_streams_agree_with_oracle(emu, oracle, nw):
     rng = random.Random(4)
     raws, caps = [], []
@@ -211,7 +211,7 @@ def test_corrupt_streams_agree_with_oracle(emu, oracle, nw):
         assert (good, final, out) == (eg, ef, eo)
 
 
-@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND, eb.STRAND_PIPE])
 def test_p2_aliasing_replay_matches_reference_digest(emu, nw):
     """phoebus.png: the inflate kernel with the decode_png aliasing parameters + the
     de-filter kernel reproduce the reference's (corrupted-tail) output."""
@@ -823,7 +823,7 @@ def test_chunked_path_random_streams_agree_with_oracle(emu, oracle, seed, chunk)
         assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
 
 
-@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND, eb.STRAND_PIPE])
 def test_randomised_dynamic_headers(emu, oracle, nw):
     """tests/header_fuzz.py: random prefix codes and a randomised run-length coding of the code-length
     sequence (16 at the start, runs across the alphabets, runs that reach behind the last length,
@@ -881,9 +881,10 @@ def test_strand_path_random_zlib_streams(emu, oracle):
         raw += c.flush()
         raws.append(raw)
         caps.append(max(len(data) + 1, len(raw)))
-    outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=eb.STRAND, in_misalign=5, out_misalign=9)
-    for raw, cap, (good, final, out, r) in zip(raws, caps, outs):
-        eg, ef, eo, st = oracle.inflate(raw, cap, want_stats=True)
-        if st.ub_flags & (0x10 | 0x02):
-            continue
-        assert (good, final, out) == (eg, ef, eo)
+    want = [oracle.inflate(raw, cap, want_stats=True) for raw, cap in zip(raws, caps)]
+    for nw in (eb.STRAND, eb.STRAND_PIPE):
+        outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, in_misalign=5, out_misalign=9)
+        for (good, final, out, r), (eg, ef, eo, st) in zip(outs, want):
+            if st.ub_flags & (0x10 | 0x02):
+                continue
+            assert (good, final, out) == (eg, ef, eo), nw

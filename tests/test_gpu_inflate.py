@@ -53,7 +53,8 @@ def _payload(rng, n, kind):
 # 0x20 = DEBIG_WAVES_CHUNKED: large streams cut into chunk tasks at block headers
 # 0x11 = DEBIG_WAVES_SPLIT_QUEUED: the pair behind persistent workgroups and a work queue
 # 0x12 = DEBIG_WAVES_STRAND: the long-segment scan (csrc/inflate_strand_kernel.inc) in front of the same LZ77 half
-WIDTHS = (1, 2, 4, 8, 0x41, 0x42, 0x10, 0x11, 0x12, 0x20)
+# 0x13 = DEBIG_WAVES_STRAND_PIPE: the same with the scan and the LZ77 half on two wavefronts of a workgroup, side by side
+WIDTHS = (1, 2, 4, 8, 0x41, 0x42, 0x10, 0x11, 0x12, 0x13, 0x20)
 
 
 def _check(oracle, gpu_device, raws, caps, widths=WIDTHS, **kw):

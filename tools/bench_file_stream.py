@@ -13,7 +13,7 @@ width = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0x10
 it = split_png(open(f, "rb").read())
 raw = it["raw"]; est = 4 * it["w"] * it["h"] + it["h"] + 1
 b = DeviceBatch.from_streams([raw] * copies, [est] * copies)
-if width in (0x10, 0x12):
+if width in (0x10, 0x12, 0x13):
     b.d_ws = torch.empty(20 * len(raw) * copies + (1 << 26), dtype=torch.uint8, device="cuda")
 for _ in range(2): b.launch(waves_per_stream=width)
 torch.cuda.synchronize()

@@ -120,6 +120,8 @@ extern "C" int emu_inflate_split_batch(const void *in, void *out, const debig_st
             if (*q != (uint64_t)n) return -2; /* a launch adds exactly n to the queue counter */
             EMU_LAUNCH(debig_scanlz_queue_kernel, grid, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
             if (*q != 2u * (uint64_t)n) return -2;
+        } else if (getenv("DEBIG_EMU_STRAND_PIPE")) { /* DEBIG_WAVES_STRAND_PIPE: scan and LZ77 wavefronts side by side */
+            EMU_LAUNCH(debig_strand_pipe_kernel, n, 128, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
         } else if (getenv("DEBIG_EMU_STRAND")) { /* DEBIG_WAVES_STRAND: the long-segment scan */
             EMU_LAUNCH(debig_strand_kernel, n, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
         } else {
