@@ -86,6 +86,8 @@ def lib():
     L.debig_hip_inflate_chunked_workspace_bytes.argtypes = [u64, u64, u32]
     L.debig_hip_png_defilter_batch.restype = C.c_int
     L.debig_hip_png_defilter_batch.argtypes = [vp, vp, vp, vp, u32, vp]
+    L.debig_hip_png_decode_fused_batch.restype = C.c_int
+    L.debig_hip_png_decode_fused_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, u64, vp]
     L.debig_hip_device_count.restype = C.c_int
     L.debig_hip_set_device.restype = C.c_int
     L.debig_hip_set_device.argtypes = [C.c_int]

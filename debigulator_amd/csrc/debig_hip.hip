@@ -12,6 +12,7 @@
 #include "inflate_strand_kernel.inc"
 #include "inflate_chunk_kernel.inc"
 #include "png_kernel.inc"
+#include "png_fused_kernel.inc"
 #include "checksum_kernel.inc"
 
 // BTYPE 1 tables, built once per device by a tiny kernel and then only copied into LDS.  Two
@@ -673,6 +674,71 @@ int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena
     hipLaunchKernelGGL(debig_png_p3_kernel, dim3(n), dim3(PNG_P3_THREADS), 0, s,
                        (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images,
                        d_results, n);
+    return (int)hipGetLastError();
+}
+
+// inflate -> de-filter in one kernel (png_fused_kernel.inc).  Per group of at most SPLIT_GROUP
+// images: plan, the fused kernel, debig_inflate_kernel for the streams the scan handed back; then, over the whole
+// batch, the one-workgroup de-filter for the images of those streams (PNG_ROW_REDO) and the P3 kernel.
+#define PNG_FUSED_NWD 2
+#define PNG_FUSED_BLK 6
+int debig_hip_png_decode_fused_batch(const void *d_in, void *d_streams_arena, const debig_stream *d_streams,
+                                     debig_result *d_results, void *d_rgba_arena, const debig_png_image *d_images,
+                                     debig_png_result *d_png_results, uint32_t n, void *d_workspace,
+                                     uint64_t workspace_bytes, void *hip_stream)
+{
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)hip_stream;
+    DeviceGuard launch_guard(launch_device(s));
+    const FixedTabs *ft = fixed_tables(s);
+    if (!ft) return (int)hipErrorOutOfMemory;
+    DefaultWs *shared = nullptr;
+    if (!d_workspace) {
+        shared = default_workspace(s);
+        if (!shared) return (int)hipErrorOutOfMemory;
+        d_workspace = shared->ptr;
+        workspace_bytes = shared->bytes;
+    }
+    // register budget of the kernel: DEBIG_FUSED_WPE = 2 | 3 (measurements); default: three workgroups per CU once the
+    // batch needs them
+    const char *we = getenv("DEBIG_FUSED_WPE");
+    const int wpe = we && *we ? (int)strtol(we, nullptr, 0) : (n > 512u ? 3 : 2);
+    int rc = 0;
+    {
+        SharedWsUse hold(shared, s);
+        if (hold.err) return hold.err;
+        for (uint32_t first = 0; first < n && rc == 0; first += SPLIT_GROUP) {
+            const uint32_t cnt = n - first < SPLIT_GROUP ? n - first : SPLIT_GROUP;
+            const uint64_t slots_bytes = align_up((uint64_t)cnt * sizeof(debig_ws_slot) + 4u * SPLIT_QUEUE_WORDS + 4u * (uint64_t)cnt, 256);
+            if (workspace_bytes < slots_bytes + (uint64_t)cnt * 1024u) { rc = (int)hipErrorInvalidValue; break; }
+            const uint64_t rest = workspace_bytes - slots_bytes;
+            const uint64_t total_recs = rest / 16u / sizeof(debig_ws_rec);
+            const uint64_t recs_bytes = align_up(total_recs * sizeof(debig_ws_rec), 256);
+            const uint64_t total_rows = (rest - recs_bytes) / 256u;
+            debig_ws_slot *slots = (debig_ws_slot *)d_workspace;
+            debig_ws_rec *recs = (debig_ws_rec *)((uint8_t *)d_workspace + slots_bytes);
+            uint32_t *rows = (uint32_t *)((uint8_t *)d_workspace + slots_bytes + recs_bytes);
+            hipLaunchKernelGGL(debig_split_plan_kernel, dim3(1), dim3(1024), 0, s, d_streams + first, cnt, slots, total_rows, total_recs);
+            if (wpe == 3)
+                hipLaunchKernelGGL((debig_png_fused_kernel<PNG_FUSED_NWD, PNG_FUSED_BLK, 3>), dim3(cnt), dim3(64 * (2 + PNG_FUSED_NWD)), 0, s,
+                                   (const uint8_t *)d_in, (uint8_t *)d_streams_arena, d_streams + first, cnt, ft->scan, slots, recs, rows,
+                                   d_results + first, (uint8_t *)d_rgba_arena, d_images + first, d_png_results + first);
+            else
+                hipLaunchKernelGGL((debig_png_fused_kernel<PNG_FUSED_NWD, PNG_FUSED_BLK, 2>), dim3(cnt), dim3(64 * (2 + PNG_FUSED_NWD)), 0, s,
+                                   (const uint8_t *)d_in, (uint8_t *)d_streams_arena, d_streams + first, cnt, ft->scan, slots, recs, rows,
+                                   d_results + first, (uint8_t *)d_rgba_arena, d_images + first, d_png_results + first);
+            hipLaunchKernelGGL(debig_inflate_kernel, dim3(cnt), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_streams_arena,
+                               d_streams + first, d_results + first, cnt, ft->one, DEBIG_CLASS_RETRY);
+            rc = (int)hipGetLastError();
+        }
+        const int frc = hold.finish();
+        if (rc == 0 && frc) rc = frc;
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(debig_png_defilter_kernel<8>, dim3(n), dim3(512), 0, s, (const uint8_t *)d_streams_arena,
+                       (uint8_t *)d_rgba_arena, d_images, d_png_results, n, 1u, (uint32_t *)nullptr, 1u);
+    hipLaunchKernelGGL(debig_png_p3_kernel, dim3(n), dim3(PNG_P3_THREADS), 0, s, (const uint8_t *)d_streams_arena,
+                       (uint8_t *)d_rgba_arena, d_images, d_png_results, n);
     return (int)hipGetLastError();
 }
 

@@ -69,6 +69,9 @@ class DevicePngBatch:
         self.s_bytes = sum(e - 1 for e in ests)
         self.d_rgba = torch.zeros(off + 64, dtype=torch.uint8, device=device)
         self.d_img = torch.frombuffer(bytearray(bytes(img)), dtype=torch.uint8).to(device)
+        self.img_host = np.frombuffer(bytes(img), dtype=np.uint8).reshape(n, C.sizeof(N.DebigPngImage)).copy()
+        self.fused = None  # launch_fused: descriptors in its own dispatch order, made on first use
+        self.last_fused = False
         self.d_ires = torch.zeros(n * C.sizeof(N.DebigPngResult), dtype=torch.uint8, device=device)
         self.lib = N.lib()
 
@@ -77,11 +80,42 @@ class DevicePngBatch:
         torch = self.torch
         if stream is None:
             stream = torch.cuda.current_stream(self.inflate.device)
+        self.last_fused = False
         self.inflate.launch(stream, waves_per_stream=waves_per_stream)
         rc = self.lib.debig_hip_png_defilter_batch(self.inflate.d_out.data_ptr(), self.d_rgba.data_ptr(),
                                                    self.d_img.data_ptr(), self.d_ires.data_ptr(), self.n,
                                                    C.c_void_p(stream.cuda_stream))
         N.check(rc, "debig_hip_png_defilter_batch")
+
+    def launch_fused(self, stream=None, workspace_bytes=None):
+        """inflate and de-filter in ONE kernel (debig_hip_png_decode_fused_batch): a workgroup per
+        image, the de-filter wavefronts a tile behind the LZ77 wavefront.  Same results as launch()."""
+        torch = self.torch
+        inf = self.inflate
+        if stream is None:
+            stream = torch.cuda.current_stream(inf.device)
+        if self.fused is None:
+            st = inf.streams_host
+            # the longest streams first (the batch ends when its slowest image does); stream i and image i stay together
+            order = np.argsort(-(st["in_len"].astype(np.int64) + st["out_cap"].astype(np.int64)), kind="stable")
+            f = {"order": order}
+            f["d_streams"] = torch.from_numpy(np.ascontiguousarray(st[order]).view(np.uint8).reshape(-1)).to(inf.device)
+            f["d_img"] = torch.from_numpy(np.ascontiguousarray(self.img_host[order]).reshape(-1)).to(inf.device)
+            f["d_res"] = torch.zeros_like(inf.d_results)
+            f["d_ires"] = torch.zeros_like(self.d_ires)
+            total_in = int(st["in_len"].sum())
+            nbytes = int(self.lib.debig_hip_inflate_workspace_bytes(total_in, self.n))
+            f["ws_bytes"] = nbytes
+            f["d_ws"] = torch.empty(nbytes, dtype=torch.uint8, device=inf.device)
+            self.fused = f
+        f = self.fused
+        wsb = f["ws_bytes"] if workspace_bytes is None else min(int(workspace_bytes), f["ws_bytes"])
+        rc = self.lib.debig_hip_png_decode_fused_batch(inf.d_in.data_ptr(), inf.d_out.data_ptr(), f["d_streams"].data_ptr(),
+                                                       f["d_res"].data_ptr(), self.d_rgba.data_ptr(), f["d_img"].data_ptr(),
+                                                       f["d_ires"].data_ptr(), self.n, f["d_ws"].data_ptr(), wsb,
+                                                       C.c_void_p(stream.cuda_stream))
+        N.check(rc, "debig_hip_png_decode_fused_batch")
+        self.last_fused = True
 
     def launch_inflate_only(self, stream=None):
         self.inflate.launch(stream)
@@ -98,6 +132,14 @@ class DevicePngBatch:
 
     def results(self):
         self.torch.cuda.synchronize()
+        if self.last_fused:  # back to the caller's order
+            from .batch import RESULT_DTYPE
+            f = self.fused
+            res = np.empty(self.n, dtype=RESULT_DTYPE)
+            res[f["order"]] = f["d_res"].cpu().numpy().view(RESULT_DTYPE)
+            ires = np.empty(self.n, dtype=np.dtype([("good", "<u4"), ("bad_row", "<u4")]))
+            ires[f["order"]] = f["d_ires"].cpu().numpy().view(ires.dtype)
+            return res, ires
         ires = self.d_ires.cpu().numpy().view(np.dtype([("good", "<u4"), ("bad_row", "<u4")]))
         return self.inflate.results(), ires
 

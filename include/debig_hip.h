@@ -12,6 +12,8 @@
  *                                by the caller (few large streams vs thousands of small ones)
  *   debig_hip_png_defilter_batch the de-filter + palette loops of decode_png()
  *                                                         src/decode_png.c:1381-1564
+ *   debig_hip_png_decode_fused_batch  inflate + de-filter of decode_png() in one kernel
+ *                                                         src/decode_png.c:800-820 -> :1381-1564
  *   debig_hip_checksum_batch     update_crc() over PNG chunks, src/decode_png.c:313-333 (and the
  *                                gzip CRC-32 / zlib Adler-32 trailers the reference never checks)
  *   debig_hip_gather             the IDAT concatenation decode_png does in the caller's buffer,
@@ -257,6 +259,23 @@ typedef struct debig_png_result {
 int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena,
                                  const debig_png_image *d_images, debig_png_result *d_results,
                                  uint32_t n, void *hip_stream);
+
+/* SURVEY.md 8(f) row 1 -- inflate AND de-filter n PNG images in ONE kernel launch (debig_png_fused_kernel):
+ * replaces the pair src/decode_png.c:800-820 (inflate of the IDAT payload) -> src/decode_png.c:1381-1564 (the row
+ * loops over the buffer it filled).  Stream i (d_streams[i]: compressed bytes in d_in, recipient inside
+ * d_streams_arena) and image i (d_images[i]: stream_off == d_streams[i].out_off) belong together.  A workgroup owns an
+ * image: one wavefront scans the DEFLATE stream, one replays it into the scanline stream, two de-filter bands of 64
+ * rows as soon as their bytes are final -- read from L2, where the same CU has just put them; the scanline stream is
+ * never read back from HBM, and the de-filter of an image no longer waits for the slowest inflate of the batch.
+ * Results are those of debig_hip_inflate_batch_ws (d_results) followed by debig_hip_png_defilter_batch
+ * (d_png_results), bit for bit: streams the scan hands back are decoded by debig_inflate_kernel and their images
+ * de-filtered by the one-workgroup kernel inside the same call; colour type 2 images with replay_p3 go to the P3
+ * kernel as always.  d_workspace / workspace_bytes: as debig_hip_inflate_batch_ws (NULL: the library's own).
+ * Meant for hundreds to a few thousand images (a workgroup of four wavefronts and 50 KB of LDS per image). */
+int debig_hip_png_decode_fused_batch(const void *d_in, void *d_streams_arena, const debig_stream *d_streams,
+                                     debig_result *d_results, void *d_rgba_arena, const debig_png_image *d_images,
+                                     debig_png_result *d_png_results, uint32_t n, void *d_workspace,
+                                     uint64_t workspace_bytes, void *hip_stream);
 
 /* A byte span of a device arena. */
 typedef struct debig_span {

@@ -13,6 +13,7 @@
 #include "../../debigulator_amd/csrc/inflate_strand_kernel.inc"
 #include "../../debigulator_amd/csrc/inflate_chunk_kernel.inc"
 #include "../../debigulator_amd/csrc/png_kernel.inc"
+#include "../../debigulator_amd/csrc/png_fused_kernel.inc"
 #include "../../debigulator_amd/csrc/checksum_kernel.inc"
 
 /* cls: DEBIG_CLASS_ALL / _SMALL / _LARGE (streams outside the class are left untouched) */
@@ -236,6 +237,47 @@ extern "C" int emu_png_defilter_mwg(const void *streams_arena, void *rgba_arena,
                1u, (uint32_t *)nullptr, 1u);
     EMU_LAUNCH(debig_png_p3_kernel, n, PNG_P3_THREADS, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images, results, n);
     free(gsync);
+    return 0;
+}
+/* SURVEY.md 8(f) row 1, as debig_hip_png_decode_fused_batch launches it: plan, the fused kernel (scan | LZ77 | two de-filter
+ * wavefronts per image), the one-kernel inflate for what the scan handed back, the one-workgroup de-filter for the images
+ * of those streams, the P3 kernel.  *n_retried = streams handed back. */
+extern "C" int emu_png_fused_batch(const void *in, void *streams_arena, const debig_stream *streams, debig_result *results,
+                                   void *rgba_arena, const debig_png_image *images, debig_png_result *png_results, uint32_t n,
+                                   uint64_t ws_bytes, uint32_t *n_retried)
+{
+    static uint32_t *ft = nullptr;
+    if (!ft) {
+        ft = (uint32_t *)calloc(1, sizeof(decltype(WaveLdsT<1>::t)));
+        EMU_LAUNCH(debig_fixed_tables_kernel<1>, 1, 64, ft);
+    }
+    static uint32_t *fts = nullptr;
+    if (!fts) {
+        fts = (uint32_t *)calloc(1, sizeof(decltype(ScanLds::t)));
+        EMU_LAUNCH(debig_scan_fixed_tables_kernel, 1, 64, fts);
+    }
+    const uint64_t slots_bytes = ((uint64_t)n * sizeof(debig_ws_slot) + 4u * SPLIT_QUEUE_WORDS + 4u * (uint64_t)n + 255) / 256 * 256;
+    if (ws_bytes < slots_bytes + (uint64_t)n * 1024u) return -1;
+    uint8_t *ws = (uint8_t *)malloc(ws_bytes);
+    memset(ws, 0xEE, ws_bytes); /* poison: nothing may be read before it is written */
+    const uint64_t rest = ws_bytes - slots_bytes;
+    const uint64_t total_recs = rest / 16u / sizeof(debig_ws_rec);
+    const uint64_t recs_bytes = (total_recs * sizeof(debig_ws_rec) + 255) / 256 * 256;
+    const uint64_t total_rows = (rest - recs_bytes) / 256u;
+    debig_ws_slot *slots = (debig_ws_slot *)ws;
+    debig_ws_rec *recs = (debig_ws_rec *)(ws + slots_bytes);
+    uint32_t *rows = (uint32_t *)(ws + slots_bytes + recs_bytes);
+    EMU_LAUNCH(debig_split_plan_kernel, 1, EMU_PLAN_THREADS, streams, n, slots, total_rows, total_recs);
+    EMU_LAUNCH((debig_png_fused_kernel<2, 6, 2>), n, 256, (const uint8_t *)in, (uint8_t *)streams_arena, streams, n, fts, slots, recs, rows,
+               results, (uint8_t *)rgba_arena, images, png_results);
+    uint32_t retried = 0;
+    for (uint32_t i = 0; i < n; i++) retried += results[i].status == DEBIG_E_RETRY;
+    if (n_retried) *n_retried = retried;
+    EMU_LAUNCH(debig_inflate_kernel, n, 64, (const uint8_t *)in, (uint8_t *)streams_arena, streams, results, n, ft, DEBIG_CLASS_RETRY);
+    EMU_LAUNCH(debig_png_defilter_kernel<8>, n, 512, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images, png_results, n,
+               1u, (uint32_t *)nullptr, 1u);
+    EMU_LAUNCH(debig_png_p3_kernel, n, PNG_P3_THREADS, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images, png_results, n);
+    free(ws);
     return 0;
 }
 extern "C" int emu_png_defilter_batch(const void *streams_arena, void *rgba_arena, const debig_png_image *images,
