@@ -703,6 +703,8 @@ int debig_hip_png_decode_fused_batch(const void *d_in, void *d_streams_arena, co
     // batch needs them
     const char *we = getenv("DEBIG_FUSED_WPE");
     const int wpe = we && *we ? (int)strtol(we, nullptr, 0) : (n > 512u ? 3 : 2);
+    const char *fe = getenv("DEBIG_FUSED_FLAGS"); /* measurements: 0 = fixed roles */
+    const uint32_t kflags = fe && *fe ? (uint32_t)strtoul(fe, nullptr, 0) : 1u;
     int rc = 0;
     {
         SharedWsUse hold(shared, s);
@@ -722,14 +724,14 @@ int debig_hip_png_decode_fused_batch(const void *d_in, void *d_streams_arena, co
             if (wpe == 3)
                 hipLaunchKernelGGL((debig_png_fused_kernel<PNG_FUSED_NWD, PNG_FUSED_BLK, 3>), dim3(cnt), dim3(64 * (2 + PNG_FUSED_NWD)), 0, s,
                                    (const uint8_t *)d_in, (uint8_t *)d_streams_arena, d_streams + first, cnt, ft->scan, slots, recs, rows,
-                                   d_results + first, (uint8_t *)d_rgba_arena, d_images + first, d_png_results + first);
+                                   d_results + first, (uint8_t *)d_rgba_arena, d_images + first, d_png_results + first, kflags);
             else
                 hipLaunchKernelGGL((debig_png_fused_kernel<PNG_FUSED_NWD, PNG_FUSED_BLK, 2>), dim3(cnt), dim3(64 * (2 + PNG_FUSED_NWD)), 0, s,
                                    (const uint8_t *)d_in, (uint8_t *)d_streams_arena, d_streams + first, cnt, ft->scan, slots, recs, rows,
-                                   d_results + first, (uint8_t *)d_rgba_arena, d_images + first, d_png_results + first);
-            hipLaunchKernelGGL(debig_inflate_kernel, dim3(cnt), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_streams_arena,
-                               d_streams + first, d_results + first, cnt, ft->one, DEBIG_CLASS_RETRY);
-            rc = (int)hipGetLastError();
+                                   d_results + first, (uint8_t *)d_rgba_arena, d_images + first, d_png_results + first, kflags);
+            // what the scan handed back: one workgroup per stream, as wide as the batch size allows
+            rc = launch_inflate(n <= 256u ? 8u : n <= 512u ? 4u : n <= 1024u ? 2u : 1u, DEBIG_CLASS_RETRY, s, d_in, d_streams_arena,
+                                d_streams + first, d_results + first, cnt, ft);
         }
         const int frc = hold.finish();
         if (rc == 0 && frc) rc = frc;

@@ -23,10 +23,13 @@ class DebigResult(C.Structure):
                 ("in_end_bits", C.c_uint64)]
 
 
-def load_emu(asan=False):
+def load_emu(asan=False, variant=None):
     name = "libdebig_emu_asan.so" if asan else "libdebig_emu.so"
+    if variant:  # e.g. "sweep": tools/simt_emu/Makefile
+        name = "libdebig_emu_%s.so" % variant
     subprocess.check_call(["make", "-s", "-C", EMU_DIR, name])
-    L = C.CDLL(os.path.join(EMU_DIR, name))
+    # DEBIG_EMU_LIB: a variant build of the same sources (e.g. -DDEBIG_NEAR_SWEEP_MIN=1: every span through the sweep)
+    L = C.CDLL(os.environ.get("DEBIG_EMU_LIB") or os.path.join(EMU_DIR, name))
     L.emu_inflate_batch.restype = C.c_int
     L.emu_inflate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
     L.emu_inflate_batch_cls.restype = C.c_int

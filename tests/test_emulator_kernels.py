@@ -888,3 +888,33 @@ def test_strand_path_random_zlib_streams(emu, oracle):
             if st.ub_flags & (0x10 | 0x02):
                 continue
             assert (good, final, out) == (eg, ef, eo), nw
+
+
+def test_near_sweep_variant_agrees_with_oracle(oracle):
+    """inflate_split_kernel.inc: the position-order near sweep (DEBIG_NEAR_SWEEP; measured, not the product's default) built
+    for EVERY span: zlib streams of text, runs and periodic data through the pair, the strand kernel, the pipeline and chunk
+    tasks (16-bit elements, matches that end behind the tile)"""
+    L = eb.load_emu(variant="sweep")
+    rng = random.Random(77)
+    raws, caps = [], []
+    for it in range(10):
+        parts = []
+        for _ in range(rng.randint(1, 4)):
+            kind, n = rng.random(), rng.randint(1500, 14000)
+            if kind < 0.4:
+                parts.append(bytes(rng.choice(b"abcdefgh \n") for _ in range(n)))
+            elif kind < 0.6:
+                parts.append(bytes([rng.randrange(256)]) * n)
+            elif kind < 0.85:
+                parts.append((bytes(rng.getrandbits(8) for _ in range(rng.randint(2, 40))) * (n // 2 + 1))[:n])
+            else:
+                parts.append(bytes(rng.getrandbits(8) for _ in range(n)))
+        c = zlib.compressobj(rng.choice([1, 6, 9]), zlib.DEFLATED, -15, 9, rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_RLE, zlib.Z_FIXED]))
+        raw = c.compress(b"".join(parts)) + c.flush()
+        raws.append(raw)
+        caps.append(max(sum(len(p) for p in parts) + 1, len(raw)))
+    want = [oracle.inflate(raw, cap) for raw, cap in zip(raws, caps)]
+    for nw, kw in ((eb.SPLIT, {}), (eb.STRAND, {}), (eb.STRAND_PIPE, {}), (eb.CHUNKED, {"chunk_bytes": 1024})):
+        outs, arena, offs = eb.emu_inflate(L, raws, caps, nw=nw, in_misalign=1, out_misalign=7, **kw)
+        for (good, final, out, r), (eg, ef, eo) in zip(outs, want):
+            assert (good, final, out) == (eg, ef, eo), hex(nw)

@@ -1,9 +1,17 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r4e
-timeout -k 10 600 python -m pytest tests/test_fused_png.py -x -q -m gpu 2>&1 | tail -15 > gpurun_out/r4e/fused_tests.txt
-cat gpurun_out/r4e/fused_tests.txt
-grep -q passed gpurun_out/r4e/fused_tests.txt && ! grep -q failed gpurun_out/r4e/fused_tests.txt || exit 1
-for wpe in 2 3; do
-echo "---- cfg3 DEBIG_FUSED_WPE=$wpe"
-DEBIG_FUSED_WPE=$wpe timeout -k 10 300 python tools/bench_png.py cfg3 2>&1 | grep -v amdgpu.ids | tail -5
-done | tee gpurun_out/r4e/cfg3_fused.txt
+L=debigulator_amd/lib
+F=tests/golden/resources
+{
+for v in base nosweep allsweep sweep32; do
+  if [ $v = base ]; then unset DEBIG_LIB; else export DEBIG_LIB=$PWD/$L/libdebigulator_hip_ab_$v.so; fi
+  echo "#### $v"
+  for f in fs_angrymob.png gimp_test.png phoebus.png purpleback.png; do python tools/bench_file_stream.py $F/$f 128 0x13 2>&1 | tail -1; done
+  python tools/bench_file_stream.py $F/fs_angrymob.png 365 0x13 2>&1 | tail -1
+  for k in fixed dynamic png; do python tools/bench_variant.py $k 4096 0x10 2>&1 | tail -1; done
+  python tools/bench_variant.py dynamic 512 0x13 1048576 2>&1 | tail -1
+  python tools/bench_variant.py png 768 0x13 1048576 2>&1 | tail -1
+  timeout -k 10 300 python tools/bench_png.py cfg3 2>&1 | grep -v amdgpu.ids | tail -4
+  timeout -k 10 300 python tools/bench_png.py cfg4 8192 8 2>&1 | grep -v amdgpu.ids | tail -4
+done
+} 2>&1 | tee gpurun_out/r4e/sweep_ab.txt

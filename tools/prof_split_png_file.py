@@ -10,12 +10,12 @@ from debigulator_amd.png_device import split_png
 which = %(which)d
 it = split_png(open(%(f)r, "rb").read())
 raw = it["raw"]; est = 4*it["w"]*it["h"] + it["h"] + 1
-raws=[raw]*64; caps=[est]*64
+NCOPY = int(os.environ.get("PROF_COPIES", "64")); raws=[raw]*NCOPY; caps=[est]*NCOPY
 b = DeviceBatch.from_streams(raws, caps)
 import ctypes
 ws = torch.empty(20*len(raw)*64 + (1<<26), dtype=torch.uint8, device="cuda")
 b.d_ws = ws
-for _ in range(2): b.launch(waves_per_stream=0x10)
+for _ in range(2): b.launch(waves_per_stream=int(os.environ.get("PROF_WIDTH", "0x10"), 0))
 torch.cuda.synchronize()
 res = b.results(); print("good", int(res["good"].sum()), "size", int(res["final_size"][0]), "C", len(raw))
 prof = res["prof"].astype(np.float64) * 16
@@ -29,7 +29,12 @@ for i, nm in enumerate(names):
 print(f"  TOTAL {tot:12.0f} cyc/stream = {tot/int(res['final_size'][0]):.1f} cyc/byte")
 '''
 from debigulator_amd.build import build
-libs = [build(extra_defs=("DEBIG_PROFILE", "DEBIG_PROFILE_LZ=%d" % w), out="libdebigulator_hip_prof%d.so" % w) for w in (0, 1)]
+LIBDIR = os.path.join(ROOT, "debigulator_amd", "lib")
+libs = [os.path.join(LIBDIR, "libdebigulator_hip_prof%d.so" % w) for w in (0, 1)]
+if os.environ.get("PROF_BUILD") or not all(os.path.exists(l) for l in libs):  # (built here, the libraries travel to the GPU box)
+    libs = [build(extra_defs=("DEBIG_PROFILE", "DEBIG_PROFILE_LZ=%d" % w), out="libdebigulator_hip_prof%d.so" % w) for w in (0, 1)]
+if os.environ.get("PROF_BUILD"):
+    sys.exit(0)
 for f in sys.argv[1:]:
     for which in (0,1):
         env = dict(os.environ, DEBIG_LIB=libs[which])

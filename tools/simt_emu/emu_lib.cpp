@@ -269,7 +269,7 @@ extern "C" int emu_png_fused_batch(const void *in, void *streams_arena, const de
     uint32_t *rows = (uint32_t *)(ws + slots_bytes + recs_bytes);
     EMU_LAUNCH(debig_split_plan_kernel, 1, EMU_PLAN_THREADS, streams, n, slots, total_rows, total_recs);
     EMU_LAUNCH((debig_png_fused_kernel<2, 6, 2>), n, 256, (const uint8_t *)in, (uint8_t *)streams_arena, streams, n, fts, slots, recs, rows,
-               results, (uint8_t *)rgba_arena, images, png_results);
+               results, (uint8_t *)rgba_arena, images, png_results, 1u);
     uint32_t retried = 0;
     for (uint32_t i = 0; i < n; i++) retried += results[i].status == DEBIG_E_RETRY;
     if (n_retried) *n_retried = retried;
