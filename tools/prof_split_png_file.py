@@ -20,7 +20,7 @@ torch.cuda.synchronize()
 res = b.results(); print("good", int(res["good"].sum()), "size", int(res["final_size"][0]), "C", len(raw))
 prof = res["prof"].astype(np.float64) * 16
 names = (["stage window", "position rounds", "full rounds (tokens)", "header + tables", "window records", "-", "TOTAL", "-"] if which == 0 else
-         ["token replay", "far copy", "near resolve", "flush", "near: round bookkeeping", "near: one-at-a-time copies", "TOTAL", "near: short copies"])
+         ["token replay", "far copy", "near resolve", "near: group set-up", "near: dependency search", "near: one-at-a-time copies (inside rounds)", "TOTAL", "near: rounds"])
 tot = prof[:, 6].mean()
 print(("scan" if which==0 else "LZ77"), "blocks", res["n_blocks"][0], "windows", res["n_windows"][0])
 for i, nm in enumerate(names):
