@@ -82,6 +82,8 @@ def lib():
     L.debig_hip_inflate_batch_ws.argtypes = [vp, vp, vp, vp, u32, u32, vp, u64, vp]
     L.debig_hip_inflate_workspace_bytes.restype = u64
     L.debig_hip_inflate_workspace_bytes.argtypes = [u64, u32]
+    L.debig_hip_inflate_workspace_bytes_io.restype = u64
+    L.debig_hip_inflate_workspace_bytes_io.argtypes = [u64, u64, u32]
     L.debig_hip_inflate_chunked_workspace_bytes.restype = u64
     L.debig_hip_inflate_chunked_workspace_bytes.argtypes = [u64, u64, u32]
     L.debig_hip_png_defilter_batch.restype = C.c_int

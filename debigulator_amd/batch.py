@@ -149,7 +149,8 @@ class DeviceBatch:
         if waves_per_stream in (N.WAVES_SPLIT, N.WAVES_SPLIT_QUEUED, N.WAVES_STRAND, N.WAVES_STRAND_PIPE):
             if self.d_ws is None:  # caller-owned workspace: nothing is allocated inside the call
                 total_in = int(self.streams_host["in_len"].sum())
-                nbytes = int(self.lib.debig_hip_inflate_workspace_bytes(total_in, self.n))
+                total_out = int(self.streams_host["out_cap"].sum())
+                nbytes = int(self.lib.debig_hip_inflate_workspace_bytes_io(total_in, total_out, self.n))
                 nbytes = int(nbytes * float(os.environ.get("DEBIG_WS_SCALE", "1")))  # experiments: a larger / smaller token workspace
                 self.d_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             ws_ptr, ws_bytes = self.d_ws.data_ptr(), self.d_ws.numel()

@@ -381,6 +381,14 @@ uint64_t debig_hip_inflate_workspace_bytes(uint64_t total_in_bytes, uint32_t n)
     const uint64_t per_group_in = n ? (total_in_bytes + n - 1) / n * group : 0; /* average streams */
     return align_up((uint64_t)group * (sizeof(debig_ws_slot) + 24576u) + per_group_in * 12u, 4096);
 }
+uint64_t debig_hip_inflate_workspace_bytes_io(uint64_t total_in_bytes, uint64_t total_out_cap, uint32_t n)
+{
+    // the plan step's second weight term (PlanStreamWeight: min(out_cap / 64, 4 in_len) per stream), 12 x as the first
+    const uint32_t group = n < SPLIT_GROUP ? n : SPLIT_GROUP;
+    const uint64_t out_term = total_out_cap / 64u < 4u * total_in_bytes ? total_out_cap / 64u : 4u * total_in_bytes;
+    const uint64_t per_group = n ? (out_term + n - 1) / n * group : 0;
+    return debig_hip_inflate_workspace_bytes(total_in_bytes, n) + align_up(per_group * 12u, 4096);
+}
 
 uint64_t debig_hip_inflate_chunked_workspace_bytes(uint64_t total_in_bytes, uint64_t total_out_bytes, uint32_t n)
 {
@@ -730,6 +738,7 @@ int debig_hip_png_decode_fused_batch(const void *d_in, void *d_streams_arena, co
                                    (const uint8_t *)d_in, (uint8_t *)d_streams_arena, d_streams + first, cnt, ft->scan, slots, recs, rows,
                                    d_results + first, (uint8_t *)d_rgba_arena, d_images + first, d_png_results + first, kflags);
             // what the scan handed back: one workgroup per stream, as wide as the batch size allows
+            if (kflags & 2u) { rc = (int)hipGetLastError(); continue; } /* DEBIG_FUSED_FLAGS & 2 (diagnostic): leave them as DEBIG_E_RETRY */
             rc = launch_inflate(n <= 256u ? 8u : n <= 512u ? 4u : n <= 1024u ? 2u : 1u, DEBIG_CLASS_RETRY, s, d_in, d_streams_arena,
                                 d_streams + first, d_results + first, cnt, ft);
         }
@@ -737,6 +746,7 @@ int debig_hip_png_decode_fused_batch(const void *d_in, void *d_streams_arena, co
         if (rc == 0 && frc) rc = frc;
     }
     if (rc) return rc;
+    if (kflags & 2u) return 0;
     hipLaunchKernelGGL(debig_png_defilter_kernel<8>, dim3(n), dim3(512), 0, s, (const uint8_t *)d_streams_arena,
                        (uint8_t *)d_rgba_arena, d_images, d_png_results, n, 1u, (uint32_t *)nullptr, 1u);
     hipLaunchKernelGGL(debig_png_p3_kernel, dim3(n), dim3(PNG_P3_THREADS), 0, s, (const uint8_t *)d_streams_arena,

@@ -292,9 +292,9 @@ int debig_launch_inflate_planned(debig_ctx *c, const void *d_in_arena, const deb
     const uint32_t w = permuted ? waves : debig_pick_waves(desc, n);
     uint64_t ws_bytes = 0;
     if (w == DEBIG_WAVES_SPLIT || w == DEBIG_WAVES_STRAND || w == DEBIG_WAVES_STRAND_PIPE) { /* the throughput paths want a token workspace sized from the input */
-        uint64_t total_in = 0;
-        for (uint32_t i = 0; i < n; i++) total_in += desc[i].in_len;
-        ws_bytes = debig_hip_inflate_workspace_bytes(total_in, n);
+        uint64_t total_in = 0, total_out = 0;
+        for (uint32_t i = 0; i < n; i++) { total_in += desc[i].in_len; total_out += desc[i].out_cap; }
+        ws_bytes = debig_hip_inflate_workspace_bytes_io(total_in, total_out, n);
         if (debig_devbuf_reserve(&c->ws, ws_bytes)) ws_bytes = 0; /* no memory: the library's own fallback */
     }
     if ((rc = debig_devbuf_reserve(&c->desc, (uint64_t)n * sizeof(debig_stream))) ||

@@ -6,6 +6,7 @@ csrc/host/debig_png.c): IDAT payloads -> input arena; then ONE inflate launch
 launch (debig_hip_png_defilter_batch).  Used by the GPU tests and tools/bench_png.py.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -33,6 +34,10 @@ def split_png(data):
         at += 12 + ln
     zz = b"".join(z)
     return {"w": w, "h": h, "ct": ct, "raw": zz[2:-4], "palette": pal}
+
+
+# where the fused kernel (one workgroup per image) beats the pair of launches: profiles/r04_fused_vs_pair.txt
+FUSED_MIN_IMAGES, FUSED_MAX_IMAGES, FUSED_MAX_STREAM = 513, 1536, 64 << 20
 
 
 class DevicePngBatch:
@@ -67,6 +72,7 @@ class DevicePngBatch:
         self.rgba_bytes = sum(4 * it["w"] * it["h"] for it in self.items)
         self.c_bytes = sum(len(r) for r in raws)
         self.s_bytes = sum(e - 1 for e in ests)
+        self.max_stream = max(ests) if ests else 0
         self.d_rgba = torch.zeros(off + 64, dtype=torch.uint8, device=device)
         self.d_img = torch.frombuffer(bytearray(bytes(img)), dtype=torch.uint8).to(device)
         self.img_host = np.frombuffer(bytes(img), dtype=np.uint8).reshape(n, C.sizeof(N.DebigPngImage)).copy()
@@ -75,8 +81,16 @@ class DevicePngBatch:
         self.d_ires = torch.zeros(n * C.sizeof(N.DebigPngResult), dtype=torch.uint8, device=device)
         self.lib = N.lib()
 
-    def launch(self, stream=None, waves_per_stream=0):
-        """waves_per_stream: inflate width (include/debig_hip.h: debig_hip_inflate_batch_ex), 0 = the batch's own plan"""
+    def launch(self, stream=None, waves_per_stream=0, fused=None):
+        """waves_per_stream: inflate width (include/debig_hip.h: debig_hip_inflate_batch_ex), 0 = the batch's own plan.
+        fused: True = one kernel per batch (launch_fused), False = inflate launch + de-filter launch, None = the faster of the
+        two for this batch by the measured rule (FUSED_MIN_IMAGES .. FUSED_MAX_IMAGES images, none above FUSED_MAX_STREAM
+        bytes of scanline stream), unless a width is asked for"""
+        if fused is None:
+            fused = (waves_per_stream == 0 and not os.environ.get("DEBIG_WAVES_PER_STREAM") and
+                     FUSED_MIN_IMAGES <= self.n <= FUSED_MAX_IMAGES and self.max_stream <= FUSED_MAX_STREAM)
+        if fused:
+            return self.launch_fused(stream)
         torch = self.torch
         if stream is None:
             stream = torch.cuda.current_stream(self.inflate.device)
@@ -103,8 +117,8 @@ class DevicePngBatch:
             f["d_img"] = torch.from_numpy(np.ascontiguousarray(self.img_host[order]).reshape(-1)).to(inf.device)
             f["d_res"] = torch.zeros_like(inf.d_results)
             f["d_ires"] = torch.zeros_like(self.d_ires)
-            total_in = int(st["in_len"].sum())
-            nbytes = int(self.lib.debig_hip_inflate_workspace_bytes(total_in, self.n))
+            total_in, total_out = int(st["in_len"].sum()), int(st["out_cap"].sum())
+            nbytes = int(self.lib.debig_hip_inflate_workspace_bytes_io(total_in, total_out, self.n))
             f["ws_bytes"] = nbytes
             f["d_ws"] = torch.empty(nbytes, dtype=torch.uint8, device=inf.device)
             self.fused = f

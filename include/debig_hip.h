@@ -198,6 +198,11 @@ int debig_hip_init(void *hip_stream);
  * path.  d_workspace = NULL: the internal cached workspace.  The workspace holds no state between
  * calls. */
 uint64_t debig_hip_inflate_workspace_bytes(uint64_t total_in_bytes, uint32_t n);
+/* The same for a caller that also knows the recipients: total_out_cap = the sum of out_cap.  Highly compressible
+ * streams (flat image areas: 30 KB for 4 MB, codes of one or two bits) write many more token units per compressed byte
+ * than 12 x allows for; the plan step gives every stream a share by in_len + min(out_cap / 64, 4 in_len) + 2 KiB, and
+ * this size adds the second term (at most 3/16 of total_out_cap), so that such streams are not handed back. */
+uint64_t debig_hip_inflate_workspace_bytes_io(uint64_t total_in_bytes, uint64_t total_out_cap, uint32_t n);
 /* workspace that lets DEBIG_WAVES_CHUNKED take every stream of a batch: total_out_bytes = the sum
  * of the recipients (out_cap), which should be close to the decoded sizes */
 uint64_t debig_hip_inflate_chunked_workspace_bytes(uint64_t total_in_bytes, uint64_t total_out_bytes, uint32_t n);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: the fused inflate -> de-filter kernel on subsets of config 3 and with larger workspaces."""
+"""Diagnostic: the fused inflate -> de-filter kernel against the pair of launches, config 3's mix of sample files at
+several batch sizes (and its two halves: the five photo-like fs_* files, the nine smaller ones)."""
 import glob, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,17 +22,14 @@ datas = {os.path.basename(f): open(f, "rb").read() for f in files}
 names = sorted(datas)
 big = [n for n in names if n.startswith("fs_")]
 small = [n for n in names if not n.startswith("fs_")]
-for label, sel, count in (("all 14 x 1024", names, 1024), ("5 fs_* x 365", big, 365), ("9 small x 659", small, 659), ("5 fs_* x 128", big, 128)):
+cases = [("all 14", names, c) for c in (32, 64, 128, 256, 512, 1024, 2048, 4096)] + [("5 fs_*", big, 365), ("9 small", small, 659)]
+for label, sel, count in cases:
     pngs = [datas[sel[i % len(sel)]] for i in range(count)]
     b = DevicePngBatch(pngs)
-    t_pair = timeit(b.launch)
+    t_pair = timeit(lambda: b.launch(fused=False))
     t_f = timeit(b.launch_fused)
-    f = b.fused
-    big_ws = torch.empty(3 * f["ws_bytes"], dtype=torch.uint8, device="cuda")
-    f["d_ws"], f["ws_bytes"] = big_ws, big_ws.numel()
-    t_f3 = timeit(b.launch_fused)
     res, ires = b.results()
     assert (res["good"] == 1).all() and (ires["good"] == 1).all()
-    print(f"{label:18s} pair {t_pair:8.3f} ms   fused {t_f:8.3f} ms   fused, 3 x workspace {t_f3:8.3f} ms   windows/stream {res['n_windows'].mean():.1f}", flush=True)
-    del b, big_ws
+    print(f"{label:8s} x {count:5d}   pair {t_pair:8.3f} ms   fused {t_f:8.3f} ms   {b.rgba_bytes / min(t_pair, t_f) / 1e6:7.1f} GB/s of RGBA at best", flush=True)
+    del b
     torch.cuda.empty_cache()
