@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4e
-python tools/probe_fused_files.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r4e/fused_files.txt
-python tools/bench_fused_probe.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r4e/fused_vs_pair.txt
+mkdir -p gpurun_out/r4f
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 | tee gpurun_out/r4f/gpu_tests.txt
