@@ -711,8 +711,8 @@ int debig_hip_png_decode_fused_batch(const void *d_in, void *d_streams_arena, co
     // batch needs them
     const char *we = getenv("DEBIG_FUSED_WPE");
     const int wpe = we && *we ? (int)strtol(we, nullptr, 0) : (n > 512u ? 3 : 2);
-    const char *fe = getenv("DEBIG_FUSED_FLAGS"); /* measurements: 0 = fixed roles */
-    const uint32_t kflags = fe && *fe ? (uint32_t)strtoul(fe, nullptr, 0) : 1u;
+    const char *fe = getenv("DEBIG_FUSED_FLAGS"); /* measurements: 0 = fixed roles, default priority; & 2: no hand-back launches */
+    const uint32_t kflags = fe && *fe ? (uint32_t)strtoul(fe, nullptr, 0) : 5u; /* 1: roles rotate, 4: raised wavefront priority */
     int rc = 0;
     {
         SharedWsUse hold(shared, s);

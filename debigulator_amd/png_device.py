@@ -38,6 +38,15 @@ def split_png(data):
 
 # where the fused kernel (one workgroup per image) beats the pair of launches: profiles/r04_fused_vs_pair.txt
 FUSED_MIN_IMAGES, FUSED_MAX_IMAGES, FUSED_MAX_STREAM = 513, 1536, 64 << 20
+# A batch of mid-size images of two kinds (config 3: photo-like files of about 1 MB of IDAT in some forty DEFLATE blocks among
+# small and highly compressible ones) is decoded as TWO batches side by side on two HIP streams: the long streams as chunk
+# tasks (DEBIG_WAVES_CHUNKED: a stream is cut at its block headers and spread over many workgroups -- 365 copies of such a
+# file: 12 .. 19 ms against 21 on a wavefront pair per stream) + one de-filter launch, the rest through the fused kernel
+# (few blocks: nothing to cut; profiles/r04_hybrid_cfg3.txt).
+# Streams of a few KB go a third way: one workgroup per stream + a de-filter launch on another side stream (such files tend to
+# be a block every few hundred bytes -- 800 blocks in 5 KB --, which the fused kernel's scan hands back: a launch behind it).
+HYBRID_LONG_IN_BYTES, HYBRID_MIN_LONG, HYBRID_MIN_IMAGES, HYBRID_MAX_IMAGES = 256 << 10, 16, 64, 4096
+HYBRID_TINY_IN_BYTES = 16 << 10
 
 
 class DevicePngBatch:
@@ -78,19 +87,31 @@ class DevicePngBatch:
         self.img_host = np.frombuffer(bytes(img), dtype=np.uint8).reshape(n, C.sizeof(N.DebigPngImage)).copy()
         self.fused = None  # launch_fused: descriptors in its own dispatch order, made on first use
         self.last_fused = False
+        self.device = device
+        self.pngs, self.strict = pngs, strict
+        self.hybrid = None  # launch_hybrid: {"long": (indices, sub-batch), "rest": (indices, sub-batch), side stream}, made on first use
+        self.last_hybrid = False
+        lens = np.array([len(r) for r in raws], dtype=np.int64)
+        self.n_long = int((lens >= HYBRID_LONG_IN_BYTES).sum())
         self.d_ires = torch.zeros(n * C.sizeof(N.DebigPngResult), dtype=torch.uint8, device=device)
         self.lib = N.lib()
 
-    def launch(self, stream=None, waves_per_stream=0, fused=None):
+    def launch(self, stream=None, waves_per_stream=0, fused=None, hybrid=None):
         """waves_per_stream: inflate width (include/debig_hip.h: debig_hip_inflate_batch_ex), 0 = the batch's own plan.
         fused: True = one kernel per batch (launch_fused), False = inflate launch + de-filter launch, None = the faster of the
         two for this batch by the measured rule (FUSED_MIN_IMAGES .. FUSED_MAX_IMAGES images, none above FUSED_MAX_STREAM
         bytes of scanline stream), unless a width is asked for"""
+        auto = fused is None and waves_per_stream == 0 and not os.environ.get("DEBIG_WAVES_PER_STREAM")
+        if hybrid is None:
+            hybrid = (auto and HYBRID_MIN_IMAGES <= self.n <= HYBRID_MAX_IMAGES and self.max_stream <= FUSED_MAX_STREAM and
+                      HYBRID_MIN_LONG <= self.n_long < self.n)
+        if hybrid:
+            return self.launch_hybrid(stream)
         if fused is None:
-            fused = (waves_per_stream == 0 and not os.environ.get("DEBIG_WAVES_PER_STREAM") and
-                     FUSED_MIN_IMAGES <= self.n <= FUSED_MAX_IMAGES and self.max_stream <= FUSED_MAX_STREAM)
+            fused = auto and FUSED_MIN_IMAGES <= self.n <= FUSED_MAX_IMAGES and self.max_stream <= FUSED_MAX_STREAM
         if fused:
             return self.launch_fused(stream)
+        self.last_hybrid = False
         torch = self.torch
         if stream is None:
             stream = torch.cuda.current_stream(self.inflate.device)
@@ -100,6 +121,45 @@ class DevicePngBatch:
                                                    self.d_img.data_ptr(), self.d_ires.data_ptr(), self.n,
                                                    C.c_void_p(stream.cuda_stream))
         N.check(rc, "debig_hip_png_defilter_batch")
+
+    def launch_hybrid(self, stream=None):
+        """the long streams as chunk tasks + a de-filter launch on a side stream, the tiny ones as a workgroup per stream + a
+        de-filter launch on another, the others through the fused kernel on `stream`; `stream` continues when all are through.
+        Same results as launch(fused=False)."""
+        torch = self.torch
+        dev = self.inflate.device
+        if stream is None:
+            stream = torch.cuda.current_stream(dev)
+        if self.hybrid is None:
+            lens = np.array([len(it["raw"]) for it in self.items], dtype=np.int64)
+            cls = {"long": np.nonzero(lens >= HYBRID_LONG_IN_BYTES)[0],
+                   "tiny": np.nonzero(lens < HYBRID_TINY_IN_BYTES)[0],
+                   "rest": np.nonzero((lens < HYBRID_LONG_IN_BYTES) & (lens >= HYBRID_TINY_IN_BYTES))[0]}
+            self.hybrid = {"parts": []}
+            for key in ("long", "rest", "tiny"):
+                idx = cls[key]
+                if len(idx):
+                    sub = DevicePngBatch([self.pngs[i] for i in idx], device=self.device, strict=self.strict)
+                    self.hybrid["parts"].append((key, idx, sub, torch.cuda.Stream(device=dev) if key != "rest" else None))
+        # the fused kernel first: its workgroups (50 KB of LDS each) are resident before the chunk tasks fill the chip, and its
+        # wavefronts run at a raised priority (latency bound, few); the side streams start from the same point of `stream`
+        ev0 = torch.cuda.Event()
+        ev0.record(stream)
+        order = sorted(self.hybrid["parts"], key=lambda p: {"rest": 0, "long": 1, "tiny": 2}[p[0]])
+        for key, idx, sub, side in order:
+            s_ = stream if side is None else side
+            if side is not None:
+                side.wait_event(ev0)
+            if key == "long":
+                sub.launch(s_, waves_per_stream=N.WAVES_CHUNKED, fused=False)
+            elif key == "rest" and sub.n >= 16:
+                sub.launch_fused(s_)
+            else:
+                sub.launch(s_, fused=False, hybrid=False)
+        for key, idx, sub, side in order:
+            if side is not None:
+                stream.wait_stream(side)
+        self.last_hybrid, self.last_fused = True, False
 
     def launch_fused(self, stream=None, workspace_bytes=None):
         """inflate and de-filter in ONE kernel (debig_hip_png_decode_fused_batch): a workgroup per
@@ -129,13 +189,15 @@ class DevicePngBatch:
                                                        f["d_ires"].data_ptr(), self.n, f["d_ws"].data_ptr(), wsb,
                                                        C.c_void_p(stream.cuda_stream))
         N.check(rc, "debig_hip_png_decode_fused_batch")
-        self.last_fused = True
+        self.last_fused, self.last_hybrid = True, False
 
     def launch_inflate_only(self, stream=None):
+        self.last_fused = self.last_hybrid = False  # (the object's own arenas: what results() / rgba() read from now on)
         self.inflate.launch(stream)
 
     def launch_defilter_only(self, stream=None):
-        """De-filter the streams a previous launch() left in HBM (timing of that kernel alone)."""
+        """De-filter the streams a previous launch_inflate_only() / launch(fused=False) left in HBM (timing of that kernel alone)."""
+        self.last_fused = self.last_hybrid = False
         torch = self.torch
         if stream is None:
             stream = torch.cuda.current_stream(self.inflate.device)
@@ -146,6 +208,14 @@ class DevicePngBatch:
 
     def results(self):
         self.torch.cuda.synchronize()
+        if self.last_hybrid:  # the two halves back in the caller's order
+            from .batch import RESULT_DTYPE
+            res = np.empty(self.n, dtype=RESULT_DTYPE)
+            ires = np.empty(self.n, dtype=np.dtype([("good", "<u4"), ("bad_row", "<u4")]))
+            for key, idx, sub, side in self.hybrid["parts"]:
+                r, ir = sub.results()
+                res[idx], ires[idx] = r, ir
+            return res, ires
         if self.last_fused:  # back to the caller's order
             from .batch import RESULT_DTYPE
             f = self.fused
@@ -158,6 +228,11 @@ class DevicePngBatch:
         return self.inflate.results(), ires
 
     def rgba(self, i):
+        if self.last_hybrid:
+            for key, idx, sub, side in self.hybrid["parts"]:
+                k = np.nonzero(idx == i)[0]
+                if len(k):
+                    return sub.rgba(int(k[0]))
         it = self.items[i]
         o = self.rgba_off[i]
         return self.d_rgba[o:o + 4 * it["w"] * it["h"]].cpu().numpy()

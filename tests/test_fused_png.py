@@ -239,3 +239,31 @@ def test_gpu_fused_streams_handed_back(gpu_device):
     for i in range(len(datas) * 2):
         name = os.path.basename(files[i % len(files)])
         assert hashlib.sha256(b.rgba(i).tobytes()).hexdigest() == gold[name]["rgba_sha256"], (i, name)
+
+
+@pytest.mark.gpu
+def test_gpu_hybrid_launch_reference_sample_files(gpu_device):
+    """what DevicePngBatch.launch() picks for a config-3-like mix: the long streams as chunk tasks on a side stream, the rest
+    through the fused kernel -- the reference's digests for every image, twice over the same buffers"""
+    import glob
+
+    from debigulator_amd.png_device import DevicePngBatch
+
+    gold = json.load(open(os.path.join(GOLD, "resources.json")))["png"]
+    files = [f for f in sorted(glob.glob(os.path.join(GOLD, "resources", "*.png"))) if not f.endswith("backgrounddetailed1.png")]
+    datas = [open(f, "rb").read() for f in files]
+    n = 5 * len(files)
+    b = DevicePngBatch([datas[i % len(datas)] for i in range(n)], device=gpu_device)
+    for rep in range(2):
+        b.launch()
+        assert b.last_hybrid
+        res, ires = b.results()
+        assert (res["good"] == 1).all() and (ires["good"] == 1).all()
+        for i in range(n) if rep == 0 else (0, 3, 17, n - 1):
+            name = os.path.basename(files[i % len(files)])
+            assert hashlib.sha256(b.rgba(i).tobytes()).hexdigest() == gold[name]["rgba_sha256"], (rep, i, name)
+    # and the same batch through the two launches
+    b.launch(fused=False)
+    assert not b.last_hybrid
+    res2, ires2 = b.results()
+    assert (res2["good"] == 1).all() and (res2["final_size"] == res["final_size"]).all()

@@ -26,10 +26,12 @@ cases = [("all 14", names, c) for c in (32, 64, 128, 256, 512, 1024, 2048, 4096)
 for label, sel, count in cases:
     pngs = [datas[sel[i % len(sel)]] for i in range(count)]
     b = DevicePngBatch(pngs)
-    t_pair = timeit(lambda: b.launch(fused=False))
+    t_pair = timeit(lambda: b.launch(fused=False, hybrid=False))
     t_f = timeit(b.launch_fused)
     res, ires = b.results()
     assert (res["good"] == 1).all() and (ires["good"] == 1).all()
-    print(f"{label:8s} x {count:5d}   pair {t_pair:8.3f} ms   fused {t_f:8.3f} ms   {b.rgba_bytes / min(t_pair, t_f) / 1e6:7.1f} GB/s of RGBA at best", flush=True)
+    t_auto = timeit(b.launch)
+    how = "hybrid" if b.last_hybrid else "fused" if b.last_fused else "pair"
+    print(f"{label:8s} x {count:5d}   pair {t_pair:8.3f} ms   fused {t_f:8.3f} ms   launch() {t_auto:8.3f} ms ({how})   {b.rgba_bytes / t_auto / 1e6:7.1f} GB/s of RGBA", flush=True)
     del b
     torch.cuda.empty_cache()
