@@ -45,7 +45,7 @@ FUSED_MIN_IMAGES, FUSED_MAX_IMAGES, FUSED_MAX_STREAM = 513, 1536, 64 << 20
 # (few blocks: nothing to cut; profiles/r04_hybrid_cfg3.txt).
 # Streams of a few KB go a third way: one workgroup per stream + a de-filter launch on another side stream (such files tend to
 # be a block every few hundred bytes -- 800 blocks in 5 KB --, which the fused kernel's scan hands back: a launch behind it).
-HYBRID_LONG_IN_BYTES, HYBRID_MIN_LONG, HYBRID_MIN_IMAGES, HYBRID_MAX_IMAGES = 256 << 10, 16, 64, 4096
+HYBRID_LONG_IN_BYTES, HYBRID_MIN_LONG, HYBRID_MIN_IMAGES, HYBRID_MAX_IMAGES = 256 << 10, 1, 8, 4096
 HYBRID_TINY_IN_BYTES = 16 << 10
 
 
@@ -102,9 +102,9 @@ class DevicePngBatch:
         two for this batch by the measured rule (FUSED_MIN_IMAGES .. FUSED_MAX_IMAGES images, none above FUSED_MAX_STREAM
         bytes of scanline stream), unless a width is asked for"""
         auto = fused is None and waves_per_stream == 0 and not os.environ.get("DEBIG_WAVES_PER_STREAM")
-        if hybrid is None:
+        if hybrid is None:  # (a batch of long streams only is one part: chunk tasks + a de-filter launch)
             hybrid = (auto and HYBRID_MIN_IMAGES <= self.n <= HYBRID_MAX_IMAGES and self.max_stream <= FUSED_MAX_STREAM and
-                      HYBRID_MIN_LONG <= self.n_long < self.n)
+                      HYBRID_MIN_LONG <= self.n_long)
         if hybrid:
             return self.launch_hybrid(stream)
         if fused is None:
@@ -140,25 +140,22 @@ class DevicePngBatch:
                 idx = cls[key]
                 if len(idx):
                     sub = DevicePngBatch([self.pngs[i] for i in idx], device=self.device, strict=self.strict)
-                    self.hybrid["parts"].append((key, idx, sub, torch.cuda.Stream(device=dev) if key != "rest" else None))
-        # the fused kernel first: its workgroups (50 KB of LDS each) are resident before the chunk tasks fill the chip, and its
-        # wavefronts run at a raised priority (latency bound, few); the side streams start from the same point of `stream`
+                    # every part on a stream of its own; the fused kernel's on a HIGH-priority one: its few, latency-bound
+                    # workgroups (50 KB of LDS each) must get their slots while the chunk tasks of the long streams fill the chip
+                    self.hybrid["parts"].append((key, idx, sub, torch.cuda.Stream(device=dev, priority=-1 if key == "rest" else 0)))
         ev0 = torch.cuda.Event()
         ev0.record(stream)
         order = sorted(self.hybrid["parts"], key=lambda p: {"rest": 0, "long": 1, "tiny": 2}[p[0]])
         for key, idx, sub, side in order:
-            s_ = stream if side is None else side
-            if side is not None:
-                side.wait_event(ev0)
+            side.wait_event(ev0)
             if key == "long":
-                sub.launch(s_, waves_per_stream=N.WAVES_CHUNKED, fused=False)
+                sub.launch(side, waves_per_stream=N.WAVES_CHUNKED, fused=False, hybrid=False)
             elif key == "rest" and sub.n >= 16:
-                sub.launch_fused(s_)
+                sub.launch_fused(side)
             else:
-                sub.launch(s_, fused=False, hybrid=False)
+                sub.launch(side, fused=False, hybrid=False)
         for key, idx, sub, side in order:
-            if side is not None:
-                stream.wait_stream(side)
+            stream.wait_stream(side)
         self.last_hybrid, self.last_fused = True, False
 
     def launch_fused(self, stream=None, workspace_bytes=None):

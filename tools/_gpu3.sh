@@ -1,7 +1,9 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r4f
-timeout -k 10 600 python -m pytest tests/test_fused_png.py tests/test_gpu_configs.py -x -q -m gpu 2>&1 | tail -4 | tee gpurun_out/r4f/hybrid_tests.txt
-grep -q passed gpurun_out/r4f/hybrid_tests.txt && ! grep -q failed gpurun_out/r4f/hybrid_tests.txt || exit 1
-{ DEBIG_BENCH_FUSED=1 timeout -k 10 300 python tools/bench_png.py cfg3 2>&1 | grep -v amdgpu.ids | tail -6
-python tools/probe_hybrid_parts.py 2>&1 | grep -v amdgpu.ids
-python tools/bench_fused_probe.py 2>&1 | grep -v amdgpu.ids; } | tee gpurun_out/r4f/hybrid_cfg3.txt
+python tools/bench_fused_probe.py 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r4f/hybrid_cfg3.txt
+{
+for spec in "dynamic 1048576" "png 1048576"; do set -- $spec
+for n in 128 256 512 1024; do
+  for w in 0 0x20; do python tools/bench_variant.py $1 $n $w $2 2>&1 | tail -1; done
+done; done
+} | tee gpurun_out/r4f/chunked_grid.txt

@@ -22,7 +22,7 @@ datas = {os.path.basename(f): open(f, "rb").read() for f in files}
 names = sorted(datas)
 big = [n for n in names if n.startswith("fs_")]
 small = [n for n in names if not n.startswith("fs_")]
-cases = [("all 14", names, c) for c in (32, 64, 128, 256, 512, 1024, 2048, 4096)] + [("5 fs_*", big, 365), ("9 small", small, 659)]
+cases = [("all 14", names, c) for c in (14, 28, 42, 64, 128, 256, 384, 512, 768, 1024, 1536, 2048, 4096)] + [("5 fs_*", big, 365), ("9 small", small, 659)]
 for label, sel, count in cases:
     pngs = [datas[sel[i % len(sel)]] for i in range(count)]
     b = DevicePngBatch(pngs)
@@ -32,6 +32,10 @@ for label, sel, count in cases:
     assert (res["good"] == 1).all() and (ires["good"] == 1).all()
     t_auto = timeit(b.launch)
     how = "hybrid" if b.last_hybrid else "fused" if b.last_fused else "pair"
-    print(f"{label:8s} x {count:5d}   pair {t_pair:8.3f} ms   fused {t_f:8.3f} ms   launch() {t_auto:8.3f} ms ({how})   {b.rgba_bytes / t_auto / 1e6:7.1f} GB/s of RGBA", flush=True)
+    t_h = timeit(lambda: b.launch(hybrid=True))
+    t_h2 = timeit(lambda: b.launch(hybrid=True))
+    t_h = f"{t_h:.3f} / {t_h2:.3f}"
+    how2 = "hybrid" if b.last_hybrid else "fused" if b.last_fused else "pair"
+    print(f"{label:8s} x {count:5d}   pair {t_pair:8.3f} ms   fused {t_f:8.3f} ms   launch() {t_auto:8.3f} ms ({how})   hybrid {t_h} ms   {b.rgba_bytes / t_auto / 1e6:7.1f} GB/s of RGBA", flush=True)
     del b
     torch.cuda.empty_cache()
