@@ -41,6 +41,7 @@ WAVES_STRAND_PIPE = 0x13  # DEBIG_WAVES_STRAND_PIPE: scan and LZ77 wavefronts si
 STRAND_PIPE_MAX_STREAMS, STRAND_PIPE_MEAN_IN_BYTES = 2048, 128 << 10  # DEBIG_STRAND_PIPE_MAX_STREAMS / _MEAN_IN_BYTES
 STRAND_MIN_STREAMS, STRAND_MAX_STREAMS = 768, 3072  # DEBIG_STRAND_MIN_STREAMS / _MAX_STREAMS: what width 0 picks
 WAVES_CHUNKED = 0x20  # include/debig_hip.h: DEBIG_WAVES_CHUNKED
+STREAM_IMAGE_ROWS = 2  # DEBIG_STREAM_IMAGE_ROWS: hint for the choice of path (filtered image rows)
 
 _lib = None
 

@@ -60,6 +60,7 @@ def pack_streams(raws, caps, in_align=16, out_align=16, in_skew=0, out_skew=0, p
 LARGE_IN_BYTES = 256 << 10  # include/debig_hip.h: DEBIG_LARGE_IN_BYTES
 LARGE_OUT_BYTES = 1 << 20   # DEBIG_LARGE_OUT_BYTES
 WAVES_LARGE4_SMALL1 = 0x41  # DEBIG_WAVES_LARGE4_SMALL1
+CHUNKED_ROWS_MIN_IN_BYTES = 256 << 10  # csrc/host/debig_ctx.h: DEBIG_CHUNKED_ROWS_MIN_IN_BYTES
 
 
 def pick_waves(streams):
@@ -71,6 +72,8 @@ def pick_waves(streams):
     if n <= 1024:
         if n and int(lens.sum()) >= n << 20:  # few streams, >= 1 MiB of input each on average
             return N.WAVES_CHUNKED
+        if n and n <= 512 and (streams["flags"] & N.STREAM_IMAGE_ROWS).all() and int(lens.min()) >= CHUNKED_ROWS_MIN_IN_BYTES:
+            return N.WAVES_CHUNKED  # filtered image rows, every stream long: chunk tasks from 256 KiB on
         if 256 < n <= N.STRAND_MIN_STREAMS and int(lens.sum()) >= n * N.STRAND_PIPE_MEAN_IN_BYTES:
             return N.WAVES_STRAND_PIPE  # long streams: scan and LZ77 half side by side
         return 0  # (8 / 4 / 2 wavefronts per stream up to 256 / 512 / 768 streams, the pipeline up to 1024)

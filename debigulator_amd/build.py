@@ -41,8 +41,8 @@ def build(force=False, verbose=False, extra_defs=(), out=None):
     inc = ["-I" + os.path.join(root, "include")]
     defs = ["-D" + d for d in extra_defs]
     for c in sorted(glob.glob(os.path.join(CSRC, "host", "*.c"))):
-        o = os.path.join(odir, os.path.basename(c) + ".o")
-        cmd = ["gcc", "-O2", "-fPIC", "-std=c11", "-D_GNU_SOURCE", "-pthread", "-Wall", "-Wextra", "-fvisibility=hidden"] + inc + ["-c", c, "-o", o]
+        o = os.path.join(odir, os.path.basename(c) + ("" if out is None else "_" + out) + ".o")  # (a variant build has its own objects)
+        cmd = ["gcc", "-O2", "-fPIC", "-std=c11", "-D_GNU_SOURCE", "-pthread", "-Wall", "-Wextra", "-fvisibility=hidden"] + inc + defs + ["-c", c, "-o", o]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -58,12 +58,25 @@ int debig_download_unpack(debig_ctx *c, const void *d_arena, uint8_t *const *dst
  * average) are 40 % slower in chunk tasks.  The line is drawn at 1 MiB of input per stream. */
 #define DEBIG_CHUNKED_MEAN_IN_BYTES (1u << 20)
 #define DEBIG_CHUNKED_LONGEST_IN_BYTES (4u << 20) /* n > 1024: one stream this long is enough */
+#ifndef DEBIG_CHUNKED_ROWS_MIN_IN_BYTES
+#define DEBIG_CHUNKED_ROWS_MIN_IN_BYTES (256u << 10) /* image rows (DEBIG_STREAM_IMAGE_ROWS): every stream at least this long */
+#endif
 static inline uint32_t debig_pick_waves(const debig_stream *desc, uint32_t n)
 {
     if (n <= 1024u) {
-        uint64_t total_in = 0;
-        for (uint32_t i = 0; i < n; i++) total_in += desc[i].in_len;
+        uint64_t total_in = 0, shortest = ~0ull;
+        uint32_t rows = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            total_in += desc[i].in_len;
+            if (desc[i].in_len < shortest) shortest = desc[i].in_len;
+            rows += (desc[i].flags & DEBIG_STREAM_IMAGE_ROWS) != 0;
+        }
         if (total_in >= (uint64_t)n * DEBIG_CHUNKED_MEAN_IN_BYTES) return DEBIG_WAVES_CHUNKED;
+        /* filtered image rows (include/debig_hip.h: DEBIG_STREAM_IMAGE_ROWS), every stream of the batch long: chunk tasks
+         * from a quarter of that size on (profiles/r04_single_stream.txt: one 1 MB sample PNG 28.7 -> 4.9 ms, 73 copies
+         * 25 -> 6 ms, 365 copies 26 -> 12..19 ms; streams of few blocks -- 100 KB that decode to 4 MB -- gain nothing,
+         * hence "every stream") */
+        if (rows == n && n <= 512u && shortest >= DEBIG_CHUNKED_ROWS_MIN_IN_BYTES) return DEBIG_WAVES_CHUNKED;
     }
     if (n <= 256u) return 8u;
     if (n <= DEBIG_STRAND_MIN_STREAMS) {

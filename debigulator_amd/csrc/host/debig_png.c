@@ -279,6 +279,7 @@ DEBIG_API int debig_decode_png_batch(const uint8_t *const *inputs, const uint64_
             /* P2: recipient = wm + 772, scratch = wm + est; the first
              * table sits at the first 16-aligned scratch byte (wm itself 16-aligned) */
             desc[i].p2_on = strict ? 0u : 1u;
+            desc[i].flags = DEBIG_STREAM_IMAGE_ROWS; /* a hint for debig_pick_waves: long IDAT streams go as chunk tasks */
             desc[i].p2_est = P[i].est;
             desc[i].p2_s0 = (int64_t)P[i].est - 772 + (int64_t)((16u - (P[i].est & 15u)) & 15u);
             in_total += debig_align16(P[i].zsize) + 16;

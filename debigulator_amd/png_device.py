@@ -59,7 +59,7 @@ class DevicePngBatch:
         raws = [it["raw"] for it in self.items]
         ests = [4 * it["w"] * it["h"] + it["h"] + 1 for it in self.items]
         p2 = None if strict else [(e - 772 + ((16 - (e & 15)) & 15), e) for e in ests]
-        in_arena, streams, out_bytes = pack_streams(raws, ests, p2=p2)
+        in_arena, streams, out_bytes = pack_streams(raws, ests, p2=p2, flags=N.STREAM_IMAGE_ROWS)
         # palettes live behind the stream arena
         pal_base = self.pal_base = out_bytes  # d_out[:pal_base]: the scanline streams
         self.inflate = DeviceBatch(in_arena, streams, out_bytes + 768 * n + 64, device, plan=True)

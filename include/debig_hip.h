@@ -52,6 +52,12 @@ typedef struct debig_stream {
  * callers outside the reference's API whose input span is not "one stream", e.g. a gzip
  * member followed by further members (debig_gunzip_batch). */
 #define DEBIG_STREAM_NO_REF_GATES 1u
+/* A HINT for the host layers' choice of path, ignored by the kernels: the stream holds filtered image rows (a PNG IDAT
+ * payload).  Such data is short matches a few bytes back, chained a dozen deep: a wavefront resolves it at the latency
+ * of its LDS, and what helps is more wavefronts per stream -- chunk tasks (DEBIG_WAVES_CHUNKED) -- already from
+ * 256 KiB of input per stream (one sample file of the reference, 1 MB of IDAT: 28.7 ms on a workgroup of eight
+ * wavefronts, 4.9 ms in chunk tasks; text of the same size is faster on the workgroup).  decode_png sets it. */
+#define DEBIG_STREAM_IMAGE_ROWS 2u
 /* Test hook (fault injection, never set by the host layer): the multi-wavefront match resolve
  * gives up at its first idle poll instead of after DEBIG_RESOLVE_IDLE_BOUND of them, so the
  * DEBIG_E_INTERNAL path can be exercised on ordinary data. */

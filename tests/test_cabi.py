@@ -212,6 +212,16 @@ def test_dispatch_plan_rules():
 
     assert plan_batch(streams([2 << 20] * 64)) == (None, N.WAVES_CHUNKED)
     assert plan_batch(streams([400 << 10] * 256)) == (None, 0)                  # 0.4 MiB on average: workgroups
+    # ... unless the caller says the streams are filtered image rows (DEBIG_STREAM_IMAGE_ROWS; decode_png does) and
+    # EVERY stream is long: chunk tasks from 256 KiB on, up to 512 streams
+    rows = streams([400 << 10] * 256)
+    rows["flags"] = N.STREAM_IMAGE_ROWS
+    assert plan_batch(rows) == (None, N.WAVES_CHUNKED)
+    rows["in_len"][7] = 30000
+    assert plan_batch(rows) == (None, 0)
+    one = streams([971497])
+    one["flags"] = N.STREAM_IMAGE_ROWS
+    assert plan_batch(one) == (None, N.WAVES_CHUNKED)
     assert plan_batch(streams([20000] * 2000 + [8 << 20])) == (None, N.WAVES_CHUNKED)
     assert plan_batch(streams([20000] * 2000 + [1 << 20])) == (None, 0x41)    # a few large among thousands: those 4-wide
     assert plan_batch(streams([20000] * 2000 + [100000])) == (None, 0)

@@ -1,9 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r4f
-python tools/bench_fused_probe.py 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r4f/hybrid_cfg3.txt
-{
-for spec in "dynamic 1048576" "png 1048576"; do set -- $spec
-for n in 128 256 512 1024; do
-  for w in 0 0x20; do python tools/bench_variant.py $1 $n $w $2 2>&1 | tail -1; done
-done; done
-} | tee gpurun_out/r4f/chunked_grid.txt
+{ echo "#### with the image-rows hint (product)"; python tools/bench_decode_png_call.py 2>&1 | grep -v amdgpu.ids
+echo "#### without (DEBIG_CHUNKED_ROWS_MIN_IN_BYTES = never)"; DEBIG_LIB=$PWD/debigulator_amd/lib/libdebigulator_hip_ab_norowshint.so python tools/bench_decode_png_call.py 2>&1 | grep -v amdgpu.ids
+} | tee gpurun_out/r4f/decode_png_call.txt
+timeout -k 10 900 python -m pytest tests/test_gpu_dropin.py -x -q -m gpu 2>&1 | tail -3
