@@ -713,14 +713,23 @@ int debig_hip_png_decode_fused_batch(const void *d_in, void *d_streams_arena, co
     const int wpe = we && *we ? (int)strtol(we, nullptr, 0) : (n > 512u ? 3 : 2);
     const char *fe = getenv("DEBIG_FUSED_FLAGS"); /* measurements: 0 = fixed roles, default priority; & 2: no hand-back launches */
     const uint32_t kflags = fe && *fe ? (uint32_t)strtoul(fe, nullptr, 0) : 5u; /* 1: roles rotate, 4: raised wavefront priority */
-    int rc = 0;
+    int rc = 0, no_ws = 0;
     {
         SharedWsUse hold(shared, s);
         if (hold.err) return hold.err;
         for (uint32_t first = 0; first < n && rc == 0; first += SPLIT_GROUP) {
             const uint32_t cnt = n - first < SPLIT_GROUP ? n - first : SPLIT_GROUP;
             const uint64_t slots_bytes = align_up((uint64_t)cnt * sizeof(debig_ws_slot) + 4u * SPLIT_QUEUE_WORDS + 4u * (uint64_t)cnt, 256);
-            if (workspace_bytes < slots_bytes + (uint64_t)cnt * 1024u) { rc = (int)hipErrorInvalidValue; break; }
+            if (workspace_bytes < slots_bytes + (uint64_t)cnt * 1024u) {
+                /* no usable workspace (as debig_hip_inflate_batch_ws): a workgroup per stream, and every image of the group
+                 * goes through the one-workgroup de-filter below */
+                const hipError_t me = hipMemsetAsync(d_png_results + first, 0, (size_t)cnt * sizeof(debig_png_result), s);
+                if (me != hipSuccess) { rc = (int)me; break; }
+                rc = launch_inflate(n <= 256u ? 8u : n <= 512u ? 4u : n <= 1024u ? 2u : 1u, 0u, s, d_in, d_streams_arena,
+                                    d_streams + first, d_results + first, cnt, ft);
+                no_ws = 1;
+                continue;
+            }
             const uint64_t rest = workspace_bytes - slots_bytes;
             const uint64_t total_recs = rest / 16u / sizeof(debig_ws_rec);
             const uint64_t recs_bytes = align_up(total_recs * sizeof(debig_ws_rec), 256);
@@ -747,6 +756,9 @@ int debig_hip_png_decode_fused_batch(const void *d_in, void *d_streams_arena, co
     }
     if (rc) return rc;
     if (kflags & 2u) return 0;
+    if (no_ws) /* some group had no workspace: the ordinary de-filter launch takes the whole batch (images the fused kernel finished
+                  are simply decoded again) */
+        return debig_hip_png_defilter_batch(d_streams_arena, d_rgba_arena, d_images, d_png_results, n, hip_stream);
     hipLaunchKernelGGL(debig_png_defilter_kernel<8>, dim3(n), dim3(512), 0, s, (const uint8_t *)d_streams_arena,
                        (uint8_t *)d_rgba_arena, d_images, d_png_results, n, 1u, (uint32_t *)nullptr, 1u);
     hipLaunchKernelGGL(debig_png_p3_kernel, dim3(n), dim3(PNG_P3_THREADS), 0, s, (const uint8_t *)d_streams_arena,

@@ -233,12 +233,14 @@ def test_gpu_fused_streams_handed_back(gpu_device):
     files = [f for f in sorted(glob.glob(os.path.join(GOLD, "resources", "*.png"))) if not f.endswith("backgrounddetailed1.png")]
     datas = [open(f, "rb").read() for f in files]
     b = DevicePngBatch(datas * 2, device=gpu_device)
-    b.launch_fused(workspace_bytes=6 << 20)  # 12 x the input would be ~ 150 MB
-    res, ires = b.results()
-    assert (res["good"] == 1).all() and (ires["good"] == 1).all()
-    for i in range(len(datas) * 2):
-        name = os.path.basename(files[i % len(files)])
-        assert hashlib.sha256(b.rgba(i).tobytes()).hexdigest() == gold[name]["rgba_sha256"], (i, name)
+    for ws in (6 << 20, 4096):  # 12 x the input would be ~ 150 MB; 4 KB: no usable workspace at all (a workgroup per stream)
+        b.d_rgba.zero_()
+        b.launch_fused(workspace_bytes=ws)
+        res, ires = b.results()
+        assert (res["good"] == 1).all() and (ires["good"] == 1).all(), ws
+        for i in range(len(datas) * 2):
+            name = os.path.basename(files[i % len(files)])
+            assert hashlib.sha256(b.rgba(i).tobytes()).hexdigest() == gold[name]["rgba_sha256"], (ws, i, name)
 
 
 @pytest.mark.gpu

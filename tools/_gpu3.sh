@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4f
-timeout -k 10 900 python bench.py --config cfg4 --images 32 --no-cpu-baseline > gpurun_out/r4f/cfg4_32.json 2> gpurun_out/r4f/cfg4_32.err; tail -c 1500 gpurun_out/r4f/cfg4_32.json
+timeout -k 10 600 python -m pytest tests/test_fused_png.py -x -q -m gpu 2>&1 | tail -4
