@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from debigulator_amd.build import build  # noqa: E402
 
-lib = build(extra_defs=("DEBIG_PROFILE",), out="libdebigulator_hip_prof.so")
+_pre = os.path.join(ROOT, "debigulator_amd", "lib", "libdebigulator_hip_prof0.so")  # (built here by tools/prof_split_png_file.py PROF_BUILD=1: travels to the GPU box)
+lib = _pre if os.path.exists(_pre) and not os.environ.get("PROF_REBUILD") else build(extra_defs=("DEBIG_PROFILE",), out="libdebigulator_hip_prof.so")
 os.environ["DEBIG_LIB"] = lib
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
