@@ -1,2 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for cb in 98304 131072 196608 262144; do echo -n "DEBIG_CHUNK_BYTES=$cb "; DEBIG_CHUNK_BYTES=$cb python tools/probe_hybrid_parts.py 2>&1 | grep -v amdgpu.ids | head -2 | tr '\n' ' '; echo; done 2>&1 | tee -a gpurun_out/r4f/chunk_bytes.txt
+mkdir -p gpurun_out/r4g
+{ python tools/probe_fused_files.py 2>&1 | grep -v amdgpu.ids | grep -v "structuredart\|fs_b\|fs_c"
+DEBIG_BENCH_FUSED=1 timeout -k 10 300 python tools/bench_png.py cfg3 2>&1 | grep -v amdgpu.ids | tail -3
+python tools/bench_fused_probe.py 2>&1 | grep -v amdgpu.ids | grep "x    64\|x   256\|x  1024\|small"; } | tee gpurun_out/r4g/rows_weight.txt
