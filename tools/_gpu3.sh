@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
+timeout -k 10 1000 bash tools/refresh_profiles.sh 2>&1 | tail -8
 mkdir -p gpurun_out/r4g
-{ python tools/probe_fused_files.py 2>&1 | grep -v amdgpu.ids | grep -v "structuredart\|fs_b\|fs_c"
-DEBIG_BENCH_FUSED=1 timeout -k 10 300 python tools/bench_png.py cfg3 2>&1 | grep -v amdgpu.ids | tail -3
-python tools/bench_fused_probe.py 2>&1 | grep -v amdgpu.ids | grep "x    64\|x   256\|x  1024\|small"; } | tee gpurun_out/r4g/rows_weight.txt
+timeout -k 10 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 | tee gpurun_out/r4g/gpu_tests_final.txt
