@@ -30,7 +30,9 @@ Default run (`--config cfg2`, no --no-cfg5): the line also carries `cfg5_strong`
 measured by the same command on the same ranks -- 65536 gzip members of 1 MiB, member i -> GPU
 i mod N, strong scaling (value, ms_per_step, roofline on C + D, max-over-ranks time) -- so the
 SCALE runs (`--gpus 1/2/4/8`, no other flag) report both the weak-scaling headline and config 5.
-`value` of the line itself stays the cfg2 headline at every N.
+`value` of the line itself stays the cfg2 headline at every N.  At N = 1 the line also carries `cfg3_png`,
+BASELINE config 3 (1024 PNGs cycled from the reference's sample files, decode_png -> RGBA, resident in HBM): what
+DevicePngBatch.launch() picks, the pair of launches and the fused kernel, digests against the reference's.
 
 `--dist`: initialise torch.distributed even at N = 1 (backend nccl = RCCL at world size 1: loads
 librccl, runs init_process_group and the shard-map broadcast on a cuda tensor).
@@ -77,6 +79,7 @@ def parse_args():
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--dist", action="store_true", help="initialise torch.distributed even at N = 1")
     ap.add_argument("--no-cfg5", action="store_true", help="cfg2: skip the cfg5_strong record")
+    ap.add_argument("--no-cfg3", action="store_true", help="cfg2: skip the cfg3_png record (rank 0 at N = 1 only)")
     ap.add_argument("--no-kinds", action="store_true", help="cfg2: skip roofline_huffman / roofline_stored / ms_with_plan / roofline_interleaved "
                     "(profiling runs: the kernel statistics then hold whole-batch launches only)")
     ap.add_argument("--cfg5-steps", type=int, default=3, help="timed steps of the cfg5_strong record")
@@ -255,6 +258,58 @@ def pmc_traffic(kernel_sources_digest, scale):
         return tj["bytes_per_launch"] * scale, tj.get("source", "profiles/pmc_traffic.json")
     except (OSError, ValueError, KeyError):
         return None, None
+
+
+def cfg3_record(torch, np, dev):
+    """BASELINE config 3 through debigulator_amd.png_device.DevicePngBatch: the pair of launches, the fused kernel
+    and what launch() picks (the three-way split), each the median of 5 launches between events on the launch stream."""
+    import glob
+    import hashlib
+
+    from debigulator_amd.png_device import DevicePngBatch
+
+    rdir = os.path.join(ROOT, "tests", "golden", "resources")
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "resources.json")))["png"]
+    files = [f for f in sorted(glob.glob(os.path.join(rdir, "*.png"))) if not f.endswith("backgrounddetailed1.png")]
+    datas = [open(f, "rb").read() for f in files]
+    b = DevicePngBatch([datas[i % len(datas)] for i in range(1024)], device=dev)
+
+    def med(fn):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return float(np.median(ts))
+
+    ms_pair = med(lambda: b.launch(fused=False, hybrid=False))
+    ms_fused = med(b.launch_fused)
+    ms_default = med(b.launch)
+    how = "three batches side by side (long streams as chunk tasks, tiny ones a workgroup each, the rest through the fused kernel)" \
+        if b.last_hybrid else ("the fused kernel" if b.last_fused else "two launches")
+    res, ires = b.results()
+    ok = bool((res["good"] == 1).all() and (ires["good"] == 1).all())
+    for i, f in enumerate(files):  # the first copy of every file against the reference-made digest
+        ok = ok and hashlib.sha256(b.rgba(i).tobytes()).hexdigest() == gold[os.path.basename(f)]["rgba_sha256"]
+    assert ok, "cfg3: an image differs from the reference's digest"
+    P, Cb, Sb = b.rgba_bytes, b.c_bytes, b.s_bytes
+    return {
+        "workload": "cfg3: 1024 PNGs cycled from 14 of the reference's sample files (tests/golden/resources), decode_png -> RGBA, "
+                    "everything resident in HBM",
+        "value": P / ms_default / 1e6, "unit": "GB/s of RGBA", "ms_per_step": ms_default,
+        "launch": how,
+        "ms_two_launches": ms_pair, "ms_fused_kernel": ms_fused,
+        "compressed_bytes": Cb, "scanline_bytes": Sb, "rgba_bytes": P,
+        "roofline": {"bound": "hbm", "achieved": (Cb + P) / ms_default / 1e6, "peak": 8000.0, "unit": "GB/s",
+                     "frac": (Cb + P) / ms_default / 1e6 / 8000.0, "traffic": None, "algorithmic_bytes": Cb + P},
+        "bit_exact_checked": "every image's good flags; sha256 of the RGBA of one copy of each file against tests/golden/resources.json "
+                             "(made by the compiled reference)",
+    }
 
 
 def kernel_sources_digest():
@@ -650,6 +705,11 @@ def main():
             if cpu5_line is not None:
                 line["cfg5_strong"]["cpu_baseline"] = cpu5_line
         del b5
+    # ---- BASELINE config 3 beside it (N = 1 only: 1024 PNGs cycled from the reference's sample files, decoded to RGBA,
+    # everything resident in HBM; data files from tests/golden/resources, digests made by the compiled reference)
+    if not cfg4 and not cfg5 and not args.no_cfg3 and world == 1 and rank == 0:
+        torch.cuda.empty_cache()
+        line["cfg3_png"] = cfg3_record(torch, np, dev)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -1,4 +1,9 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 1000 bash tools/refresh_profiles.sh 2>&1 | tail -8
 mkdir -p gpurun_out/r4g
-timeout -k 10 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 | tee gpurun_out/r4g/gpu_tests_final.txt
+( time timeout -k 10 900 python bench.py > gpurun_out/r4g/bench_line.json 2> gpurun_out/r4g/bench_err.txt ) 2>&1 | tail -3
+python3 -c "
+import json
+d=json.loads(open('gpurun_out/r4g/bench_line.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'])
+print(json.dumps(d['cfg3_png'], indent=1)[:1500])"
+tail -3 gpurun_out/r4g/bench_err.txt

@@ -13,7 +13,7 @@ python3 tools/pmc_summary.py > $O/pmc_traffic.txt 2>&1
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
 echo "[refresh] kernel stats"
 ( cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_blend -- python3 $R/bench.py --steps 20 --no-cpu-baseline --no-cfg5 --no-kinds > $O/prof_blend.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_blend -- python3 $R/bench.py --steps 20 --no-cpu-baseline --no-cfg5 --no-cfg3 --no-kinds > $O/prof_blend.log 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fixed -- python3 $R/tools/bench_variant.py fixed 4096 0 > $O/prof_fixed.log 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stored -- python3 $R/tools/bench_variant.py stored 4096 0 > $O/prof_stored.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_cal -- $R/tools/bin/ubench_fetch > $O/fetch_cal.log 2>&1 )
