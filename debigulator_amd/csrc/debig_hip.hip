@@ -234,6 +234,26 @@ static uint32_t scanlz_resident_workgroups()
     return cap[dev];
 }
 
+// streams up to which the strand pipeline runs with the large LZ77 tile: what the device holds at once of that instantiation
+// (DEBIG_PIPE_BIG_TILE_STREAMS overrides: tests, measurements; 0 = never)
+static uint32_t pipe_big_tile_streams()
+{
+    const char *e = getenv("DEBIG_PIPE_BIG_TILE_STREAMS");
+    if (e && *e) return (uint32_t)strtoul(e, nullptr, 0);
+    static uint32_t cap[64];
+    static std::mutex cap_mutex;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1280u;
+    std::lock_guard<std::mutex> lock(cap_mutex);
+    if (cap[dev] == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, debig_strand_pipe_kernel<LzLdsBig>, 128, 0) != hipSuccess || per_cu <= 0) per_cu = 5;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cap[dev] = (uint32_t)per_cu * (uint32_t)cus;
+    }
+    return cap[dev];
+}
+
 static int launch_split_group(hipStream_t s, const void *d_in, void *d_out, const debig_stream *d_streams,
                               debig_result *d_results, uint32_t n, const FixedTabs *tabs, void *ws, uint64_t ws_bytes,
                               int what = 3, int queued = 0)
@@ -256,8 +276,14 @@ static int launch_split_group(hipStream_t s, const void *d_in, void *d_out, cons
 #if DEBIG_SPLIT_FUSED
     const uint32_t cap = queued == 1 ? scanlz_resident_workgroups() : 0u;
     if (queued == 3) /* DEBIG_WAVES_STRAND_PIPE: the same two halves on two wavefronts of a workgroup, record by record */
-        hipLaunchKernelGGL(debig_strand_pipe_kernel, dim3(n), dim3(128), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, n,
-                           tabs->scan, slots, recs, rows, d_results);
+    {   /* a 12 KB LZ77 tile while the device holds every stream at once with it (29 KB of LDS: 5 workgroups per CU) */
+        if (n <= pipe_big_tile_streams())
+            hipLaunchKernelGGL(debig_strand_pipe_kernel<LzLdsBig>, dim3(n), dim3(128), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, n,
+                               tabs->scan, slots, recs, rows, d_results);
+        else
+            hipLaunchKernelGGL(debig_strand_pipe_kernel<LzLds>, dim3(n), dim3(128), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, n,
+                               tabs->scan, slots, recs, rows, d_results);
+    }
     else if (queued == 2) /* DEBIG_WAVES_STRAND: the long-segment scan in front of the same LZ77 half */
         hipLaunchKernelGGL(debig_strand_kernel, dim3(n), dim3(64), 0, s, (const uint8_t *)d_in, (uint8_t *)d_out, d_streams, n,
                            tabs->scan, slots, recs, rows, d_results);
@@ -739,11 +765,11 @@ int debig_hip_png_decode_fused_batch(const void *d_in, void *d_streams_arena, co
             uint32_t *rows = (uint32_t *)((uint8_t *)d_workspace + slots_bytes + recs_bytes);
             hipLaunchKernelGGL(debig_split_plan_kernel, dim3(1), dim3(1024), 0, s, d_streams + first, cnt, slots, total_rows, total_recs);
             if (wpe == 3)
-                hipLaunchKernelGGL((debig_png_fused_kernel<PNG_FUSED_NWD, PNG_FUSED_BLK, 3>), dim3(cnt), dim3(64 * (2 + PNG_FUSED_NWD)), 0, s,
+                hipLaunchKernelGGL((debig_png_fused_kernel<PNG_FUSED_NWD, PNG_FUSED_BLK, 3, LzLds>), dim3(cnt), dim3(64 * (2 + PNG_FUSED_NWD)), 0, s,
                                    (const uint8_t *)d_in, (uint8_t *)d_streams_arena, d_streams + first, cnt, ft->scan, slots, recs, rows,
                                    d_results + first, (uint8_t *)d_rgba_arena, d_images + first, d_png_results + first, kflags);
-            else
-                hipLaunchKernelGGL((debig_png_fused_kernel<PNG_FUSED_NWD, PNG_FUSED_BLK, 2>), dim3(cnt), dim3(64 * (2 + PNG_FUSED_NWD)), 0, s,
+            else /* two workgroups per CU by registers anyway: the 12 KB LZ77 tile fits beside them (61 KB of LDS each) */
+                hipLaunchKernelGGL((debig_png_fused_kernel<PNG_FUSED_NWD, PNG_FUSED_BLK, 2, LzLdsBig>), dim3(cnt), dim3(64 * (2 + PNG_FUSED_NWD)), 0, s,
                                    (const uint8_t *)d_in, (uint8_t *)d_streams_arena, d_streams + first, cnt, ft->scan, slots, recs, rows,
                                    d_results + first, (uint8_t *)d_rgba_arena, d_images + first, d_png_results + first, kflags);
             // what the scan handed back: one workgroup per stream, as wide as the batch size allows

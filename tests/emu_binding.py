@@ -52,6 +52,7 @@ SPLIT = 0x10  # nw code of the scan / LZ77 kernel pair (include/debig_hip.h: DEB
 SPLIT_QUEUED = 0x11  # the same behind persistent workgroups and a work queue (DEBIG_WAVES_SPLIT_QUEUED): 3 workgroups, run twice
 STRAND = 0x12  # the long-segment scan behind the same LZ77 half (DEBIG_WAVES_STRAND)
 STRAND_PIPE = 0x13  # the same two halves on two wavefronts of a workgroup, record by record (DEBIG_WAVES_STRAND_PIPE)
+STRAND_PIPE_BIG = 0x113  # (test code only) the same with the 12 KB LZ77 tile the shim uses while the device holds every stream
 last_split_retried = 0  # streams the pair handed to the one-kernel path in the last SPLIT call
 
 
@@ -96,7 +97,7 @@ def emu_inflate(L, raws, caps, grid=0, nw=1, classes=None, ws_bytes=None, chunk_
         for w, cls in classes:
             rc |= L.emu_inflate_batch_cls(in_arena.ctypes.data, out_arena.ctypes.data, streams, results,
                                           len(raws), grid, w, cls)
-    elif nw in (SPLIT, SPLIT_QUEUED, STRAND, STRAND_PIPE):
+    elif nw in (SPLIT, SPLIT_QUEUED, STRAND, STRAND_PIPE, STRAND_PIPE_BIG):
         if ws_bytes is None:
             ws_bytes = len(raws) * (32 + 24576) + 9 * sum(len(r) for r in raws)
         nr = C.c_uint32(0)
@@ -104,8 +105,10 @@ def emu_inflate(L, raws, caps, grid=0, nw=1, classes=None, ws_bytes=None, chunk_
             os.environ["DEBIG_EMU_SPLIT_QUEUED"] = "1"
         if nw == STRAND:
             os.environ["DEBIG_EMU_STRAND"] = "1"
-        if nw == STRAND_PIPE:
+        if nw in (STRAND_PIPE, STRAND_PIPE_BIG):
             os.environ["DEBIG_EMU_STRAND_PIPE"] = "1"
+        if nw == STRAND_PIPE_BIG:
+            os.environ["DEBIG_EMU_PIPE_BIG_TILE"] = "1"
         try:
             rc = L.emu_inflate_split_batch(in_arena.ctypes.data, out_arena.ctypes.data, streams, results, len(raws),
                                            ws_bytes, C.byref(nr))
@@ -113,6 +116,7 @@ def emu_inflate(L, raws, caps, grid=0, nw=1, classes=None, ws_bytes=None, chunk_
             os.environ.pop("DEBIG_EMU_SPLIT_QUEUED", None)
             os.environ.pop("DEBIG_EMU_STRAND", None)
             os.environ.pop("DEBIG_EMU_STRAND_PIPE", None)
+            os.environ.pop("DEBIG_EMU_PIPE_BIG_TILE", None)
         last_split_retried = nr.value
     elif nw == CHUNKED:
         if ws_bytes is None:

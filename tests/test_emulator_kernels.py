@@ -26,10 +26,10 @@ def emu():
 
 
 # wavefronts per stream: 1 = debig_inflate_kernel, 2 / 4 = debig_inflate_mw_kernel<NW>
-@pytest.mark.parametrize("nw", [1, 2, 4, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND, eb.STRAND_PIPE])
+@pytest.mark.parametrize("nw", [1, 2, 4, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND, eb.STRAND_PIPE, eb.STRAND_PIPE_BIG])
 def test_known_answers_and_corpus(emu, nw):
     items = json.load(open(os.path.join(GOLD, "kat.json")))
-    items += json.load(open(os.path.join(GOLD, "corpus_zlib.json")))[:80 if nw in (1, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND, eb.STRAND_PIPE) else 40]
+    items += json.load(open(os.path.join(GOLD, "corpus_zlib.json")))[:80 if nw in (1, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND, eb.STRAND_PIPE, eb.STRAND_PIPE_BIG) else 40]
     raws = [bytes.fromhex(k["raw_hex"]) for k in items]
     caps = [k["recipient_size"] for k in items]
     outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, in_misalign=3, out_misalign=5)
@@ -44,10 +44,10 @@ def test_known_answers_and_corpus(emu, nw):
         assert (arena[oo + cap:oo + cap + 32] == 0xA5).all()
 
 
-@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND, eb.STRAND_PIPE])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND, eb.STRAND_PIPE, eb.STRAND_PIPE_BIG])
 def test_corrupt_corpus_reference_made(emu, nw):
     """tests/golden/corpus_corrupt.json: damaged streams with the REFERENCE's own answers (build B)"""
-    items = json.load(open(os.path.join(GOLD, "corpus_corrupt.json")))[:: 1 if nw in (1, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND, eb.STRAND_PIPE) else 3]
+    items = json.load(open(os.path.join(GOLD, "corpus_corrupt.json")))[:: 1 if nw in (1, eb.SPLIT, eb.SPLIT_QUEUED, eb.STRAND, eb.STRAND_PIPE, eb.STRAND_PIPE_BIG) else 3]
     raws = [bytes.fromhex(k["raw_hex"]) for k in items]
     caps = [k["recipient_size"] for k in items]
     outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, out_misalign=1)
@@ -211,7 +211,7 @@ def test_corrupt_streams_agree_with_oracle(emu, oracle, nw):
         assert (good, final, out) == (eg, ef, eo)
 
 
-@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND, eb.STRAND_PIPE])
+@pytest.mark.parametrize("nw", [1, 4, eb.SPLIT, eb.STRAND, eb.STRAND_PIPE, eb.STRAND_PIPE_BIG])
 def test_p2_aliasing_replay_matches_reference_digest(emu, nw):
     """phoebus.png: the inflate kernel with the decode_png aliasing parameters + the
     de-filter kernel reproduce the reference's (corrupted-tail) output."""
@@ -882,7 +882,7 @@ def test_strand_path_random_zlib_streams(emu, oracle):
         raws.append(raw)
         caps.append(max(len(data) + 1, len(raw)))
     want = [oracle.inflate(raw, cap, want_stats=True) for raw, cap in zip(raws, caps)]
-    for nw in (eb.STRAND, eb.STRAND_PIPE):
+    for nw in (eb.STRAND, eb.STRAND_PIPE, eb.STRAND_PIPE_BIG):
         outs, arena, offs = eb.emu_inflate(emu, raws, caps, nw=nw, in_misalign=5, out_misalign=9)
         for (good, final, out, r), (eg, ef, eo, st) in zip(outs, want):
             if st.ub_flags & (0x10 | 0x02):
@@ -914,7 +914,7 @@ def test_near_sweep_variant_agrees_with_oracle(oracle):
         raws.append(raw)
         caps.append(max(sum(len(p) for p in parts) + 1, len(raw)))
     want = [oracle.inflate(raw, cap) for raw, cap in zip(raws, caps)]
-    for nw, kw in ((eb.SPLIT, {}), (eb.STRAND, {}), (eb.STRAND_PIPE, {}), (eb.CHUNKED, {"chunk_bytes": 1024})):
+    for nw, kw in ((eb.SPLIT, {}), (eb.STRAND, {}), (eb.STRAND_PIPE, {}), (eb.STRAND_PIPE_BIG, {}), (eb.CHUNKED, {"chunk_bytes": 1024})):
         outs, arena, offs = eb.emu_inflate(L, raws, caps, nw=nw, in_misalign=1, out_misalign=7, **kw)
         for (good, final, out, r), (eg, ef, eo) in zip(outs, want):
             assert (good, final, out) == (eg, ef, eo), hex(nw)

@@ -122,7 +122,10 @@ extern "C" int emu_inflate_split_batch(const void *in, void *out, const debig_st
             EMU_LAUNCH(debig_scanlz_queue_kernel, grid, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
             if (*q != 2u * (uint64_t)n) return -2;
         } else if (getenv("DEBIG_EMU_STRAND_PIPE")) { /* DEBIG_WAVES_STRAND_PIPE: scan and LZ77 wavefronts side by side */
-            EMU_LAUNCH(debig_strand_pipe_kernel, n, 128, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
+            if (getenv("DEBIG_EMU_PIPE_BIG_TILE")) /* the 12 KB LZ77 tile (what the shim launches while the device holds every stream) */
+                EMU_LAUNCH(debig_strand_pipe_kernel<LzLdsBig>, n, 128, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
+            else
+                EMU_LAUNCH(debig_strand_pipe_kernel<LzLds>, n, 128, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
         } else if (getenv("DEBIG_EMU_STRAND")) { /* DEBIG_WAVES_STRAND: the long-segment scan */
             EMU_LAUNCH(debig_strand_kernel, n, 64, (const uint8_t *)in, (uint8_t *)out, streams, n, fts, slots, recs, rows, results);
         } else {
@@ -268,7 +271,7 @@ extern "C" int emu_png_fused_batch(const void *in, void *streams_arena, const de
     debig_ws_rec *recs = (debig_ws_rec *)(ws + slots_bytes);
     uint32_t *rows = (uint32_t *)(ws + slots_bytes + recs_bytes);
     EMU_LAUNCH(debig_split_plan_kernel, 1, EMU_PLAN_THREADS, streams, n, slots, total_rows, total_recs);
-    EMU_LAUNCH((debig_png_fused_kernel<2, 6, 2>), n, 256, (const uint8_t *)in, (uint8_t *)streams_arena, streams, n, fts, slots, recs, rows,
+    EMU_LAUNCH((debig_png_fused_kernel<2, 6, 2, LzLdsBig>), n, 256, (const uint8_t *)in, (uint8_t *)streams_arena, streams, n, fts, slots, recs, rows,
                results, (uint8_t *)rgba_arena, images, png_results, 1u);
     uint32_t retried = 0;
     for (uint32_t i = 0; i < n; i++) retried += results[i].status == DEBIG_E_RETRY;
