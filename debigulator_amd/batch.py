@@ -181,12 +181,20 @@ class DeviceBatch:
                                                  C.c_void_p(stream.cuda_stream))
         N.check(rc, "debig_hip_inflate_batch_ws")
 
-    def _launch_chunked(self, stream):
+    def _launch_chunked(self, stream, after_group=None, max_group=0, lanes=None):
         """The chunk-parallel path for few large streams: the batch goes through in groups of
         streams whose workspace need (debig_hip_inflate_chunked_workspace_bytes) fits
-        the free device memory less an eighth (DEBIG_CHUNKED_WS_MB overrides); one workspace, reused group after group."""
+        the free device memory less an eighth (DEBIG_CHUNKED_WS_MB overrides); one workspace, reused group after group.
+        after_group(first, count): called when a group's launches are enqueued (dispatch-order positions: what a caller
+        chains behind that group's streams, DevicePngBatch's de-filter); max_group: at most that many streams in a group;
+        lanes: HIP streams that take the groups in turn, each with a workspace of its own (group k's launches go to
+        lanes[k % len(lanes)] and run beside the other lanes' groups; after_group gets the lane as third argument; the
+        caller orders `stream` and the lanes)."""
         torch = self.torch
+        if self.chunk_groups is not None and getattr(self, "_chunk_max_group", 0) != max_group:
+            self.chunk_groups = None
         if self.chunk_groups is None:
+            self._chunk_max_group = max_group
             # few, large groups (every group pays the window kernel's serial walk and a dozen launch tails:
             # profiles/r03_chunk_workspace_groups.txt): a group may take what the device has free, less an
             # eighth (at least 40 GiB asked for); DEBIG_CHUNKED_WS_MB overrides.  Same rule as csrc/host/debig_ctx.c
@@ -211,22 +219,36 @@ class DeviceBatch:
                 groups.append((first, self.n - first))
                 return groups, max(biggest, need(tin, tout, self.n - first))
 
-            groups, biggest = carve(self.n)
+            groups, biggest = carve(max_group if max_group else self.n)
             groups, biggest = carve(-(-self.n // len(groups)))  # evened out: as many streams in each as the fullest needs
             self.chunk_groups = groups
+            self.d_ws_lanes = []
+            self.d_ws_chunked = None
             try:
                 self.d_ws_chunked = torch.empty(biggest, dtype=torch.uint8, device=self.device)
             except RuntimeError:  # out of device memory: the library falls back to whole workgroups per stream
                 self.d_ws_chunked = None
+            self.d_ws_lanes = [self.d_ws_chunked]
+        nl = min(len(lanes), len(self.chunk_groups)) if lanes else 1
+        while len(self.d_ws_lanes) < nl and self.d_ws_chunked is not None:
+            try:
+                self.d_ws_lanes.append(torch.empty_like(self.d_ws_chunked))
+            except RuntimeError:  # no room for another workspace: fewer lanes
+                break
+        nl = min(nl, len(self.d_ws_lanes))
         ssz, rsz = STREAM_DTYPE.itemsize, RESULT_DTYPE.itemsize
-        for first, count in self.chunk_groups:
+        for k, (first, count) in enumerate(self.chunk_groups):
+            ws = self.d_ws_lanes[k % nl]
+            on = lanes[k % nl] if lanes else stream
             rc = self.lib.debig_hip_inflate_batch_ws(self.d_in.data_ptr(), self.d_out.data_ptr(),
                                                      self.d_streams.data_ptr() + first * ssz,
                                                      self.d_results.data_ptr() + first * rsz, count, N.WAVES_CHUNKED,
-                                                     self.d_ws_chunked.data_ptr() if self.d_ws_chunked is not None else None,
-                                                     self.d_ws_chunked.numel() if self.d_ws_chunked is not None else 0,
-                                                     C.c_void_p(stream.cuda_stream))
+                                                     ws.data_ptr() if ws is not None else None,
+                                                     ws.numel() if ws is not None else 0,
+                                                     C.c_void_p(on.cuda_stream))
             N.check(rc, "debig_hip_inflate_batch_ws")
+            if after_group is not None:
+                after_group(first, count, on)
 
     def results(self):
         """results in the caller's stream order"""

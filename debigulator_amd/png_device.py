@@ -47,6 +47,9 @@ FUSED_MIN_IMAGES, FUSED_MAX_IMAGES, FUSED_MAX_STREAM = 513, 1536, 64 << 20
 # be a block every few hundred bytes -- 800 blocks in 5 KB --, which the fused kernel's scan hands back: a launch behind it).
 HYBRID_LONG_IN_BYTES, HYBRID_MIN_LONG, HYBRID_MIN_IMAGES, HYBRID_MAX_IMAGES = 256 << 10, 1, 8, 4096
 HYBRID_TINY_IN_BYTES = 16 << 10
+# Few large images whose streams go as chunk tasks (config 4): the de-filter of one group of images beside the inflate of the
+# next (launch_pipelined); groups of PIPE_GROUP_IMAGES images (the workspace may allow more per group).
+PIPE_MIN_IMAGES, PIPE_GROUP_IMAGES, PIPE_LANES = 4, 8, 1
 
 
 class DevicePngBatch:
@@ -89,6 +92,7 @@ class DevicePngBatch:
         self.last_fused = False
         self.device = device
         self.pngs, self.strict = pngs, strict
+        self.piped, self.last_piped = None, False  # launch_pipelined: image descriptors in dispatch order, side stream
         self.hybrid = None  # launch_hybrid: {"long": (indices, sub-batch), "rest": (indices, sub-batch), side stream}, made on first use
         self.last_hybrid = False
         lens = np.array([len(r) for r in raws], dtype=np.int64)
@@ -115,12 +119,61 @@ class DevicePngBatch:
         torch = self.torch
         if stream is None:
             stream = torch.cuda.current_stream(self.inflate.device)
-        self.last_fused = False
+        self.last_fused = self.last_piped = False
+        if (auto and self.inflate.planned_waves == N.WAVES_CHUNKED and self.n >= PIPE_MIN_IMAGES and
+                os.environ.get("DEBIG_PNG_PIPELINE", "0") == "1"):
+            return self.launch_pipelined(stream)
         self.inflate.launch(stream, waves_per_stream=waves_per_stream)
         rc = self.lib.debig_hip_png_defilter_batch(self.inflate.d_out.data_ptr(), self.d_rgba.data_ptr(),
                                                    self.d_img.data_ptr(), self.d_ires.data_ptr(), self.n,
                                                    C.c_void_p(stream.cuda_stream))
         N.check(rc, "debig_hip_png_defilter_batch")
+
+    def launch_pipelined(self, stream=None, group_images=None, lanes=None):
+        """Few large images (config 4: chunk tasks): the inflate goes through in groups of streams anyway (one workspace,
+        reused); the de-filter of a group's images runs on a side stream while the next group inflates -- it fills the slots
+        the inflate's serial and narrow launches (window walk, chain, repair, carve) leave idle.  Same results as launch()."""
+        torch = self.torch
+        inf = self.inflate
+        dev = inf.device
+        if stream is None:
+            stream = torch.cuda.current_stream(dev)
+        if group_images is None:
+            group_images = int(os.environ.get("DEBIG_PNG_PIPE_GROUP", "0")) or PIPE_GROUP_IMAGES
+        if lanes is None:
+            lanes = int(os.environ.get("DEBIG_PNG_PIPE_LANES", "0")) or PIPE_LANES
+        if self.piped is None:
+            order = inf.order if inf.order is not None else np.arange(self.n)
+            self.piped = {"order": np.asarray(order),
+                          "d_img": torch.from_numpy(np.ascontiguousarray(self.img_host[order]).reshape(-1)).to(dev),
+                          "d_ires": torch.zeros_like(self.d_ires),
+                          "side": torch.cuda.Stream(device=dev, priority=-1), "lanes": []}
+        p = self.piped
+        side = p["side"]
+        while len(p["lanes"]) < lanes:
+            p["lanes"].append(torch.cuda.Stream(device=dev))
+        isz, rsz = C.sizeof(N.DebigPngImage), C.sizeof(N.DebigPngResult)
+        ev0 = torch.cuda.Event()
+        ev0.record(stream)
+        for ln in p["lanes"][:lanes]:
+            ln.wait_event(ev0)
+
+        def after_group(first, count, on):
+            # the de-filter launches all go to ONE side stream (they share the library's progress counters; a group's
+            # de-filter is short beside its inflate), behind the event of their group's inflate
+            ev = torch.cuda.Event()
+            ev.record(on)
+            side.wait_event(ev)
+            rc = self.lib.debig_hip_png_defilter_batch(inf.d_out.data_ptr(), self.d_rgba.data_ptr(),
+                                                       p["d_img"].data_ptr() + first * isz, p["d_ires"].data_ptr() + first * rsz,
+                                                       count, C.c_void_p(side.cuda_stream))
+            N.check(rc, "debig_hip_png_defilter_batch")
+
+        inf._launch_chunked(stream, after_group=after_group, max_group=group_images, lanes=p["lanes"][:lanes])
+        for ln in p["lanes"][:lanes]:
+            stream.wait_stream(ln)
+        stream.wait_stream(side)
+        self.last_piped, self.last_fused, self.last_hybrid = True, False, False
 
     def launch_hybrid(self, stream=None):
         """the long streams as chunk tasks + a de-filter launch on a side stream, the tiny ones as a workgroup per stream + a
@@ -156,7 +209,7 @@ class DevicePngBatch:
                 sub.launch(side, fused=False, hybrid=False)
         for key, idx, sub, side in order:
             stream.wait_stream(side)
-        self.last_hybrid, self.last_fused = True, False
+        self.last_hybrid, self.last_fused, self.last_piped = True, False, False
 
     def launch_fused(self, stream=None, workspace_bytes=None):
         """inflate and de-filter in ONE kernel (debig_hip_png_decode_fused_batch): a workgroup per
@@ -186,15 +239,15 @@ class DevicePngBatch:
                                                        f["d_ires"].data_ptr(), self.n, f["d_ws"].data_ptr(), wsb,
                                                        C.c_void_p(stream.cuda_stream))
         N.check(rc, "debig_hip_png_decode_fused_batch")
-        self.last_fused, self.last_hybrid = True, False
+        self.last_fused, self.last_hybrid, self.last_piped = True, False, False
 
     def launch_inflate_only(self, stream=None):
-        self.last_fused = self.last_hybrid = False  # (the object's own arenas: what results() / rgba() read from now on)
+        self.last_fused = self.last_hybrid = self.last_piped = False  # (the object's own arenas: what results() / rgba() read from now on)
         self.inflate.launch(stream)
 
     def launch_defilter_only(self, stream=None):
         """De-filter the streams a previous launch_inflate_only() / launch(fused=False) left in HBM (timing of that kernel alone)."""
-        self.last_fused = self.last_hybrid = False
+        self.last_fused = self.last_hybrid = self.last_piped = False
         torch = self.torch
         if stream is None:
             stream = torch.cuda.current_stream(self.inflate.device)
@@ -221,6 +274,10 @@ class DevicePngBatch:
             ires = np.empty(self.n, dtype=np.dtype([("good", "<u4"), ("bad_row", "<u4")]))
             ires[f["order"]] = f["d_ires"].cpu().numpy().view(ires.dtype)
             return res, ires
+        if self.last_piped:  # back to the caller's order
+            ires = np.empty(self.n, dtype=np.dtype([("good", "<u4"), ("bad_row", "<u4")]))
+            ires[self.piped["order"]] = self.piped["d_ires"].cpu().numpy().view(ires.dtype)
+            return self.inflate.results(), ires
         ires = self.d_ires.cpu().numpy().view(np.dtype([("good", "<u4"), ("bad_row", "<u4")]))
         return self.inflate.results(), ires
 

@@ -226,6 +226,34 @@ def test_drop_in_decode_gz_batch(gpu_device):
     assert good == 1 and out == plain.tobytes()
 
 
+def test_decode_png_pipelined_groups_and_lanes(gpu_device, oracle, monkeypatch):
+    """DevicePngBatch.launch_pipelined (opt-in: DEBIG_PNG_PIPELINE=1): the inflate in groups of images through chunk tasks
+    on one and on two lanes (a workspace each), every group's de-filter on a side stream behind it -- against the oracle's
+    decode_png, image for image, results in the caller's order."""
+    import random
+
+    from debigulator_amd.png_device import DevicePngBatch
+
+    rng = random.Random(7)
+    pngs = []
+    for it in range(21):
+        w, h = rng.randint(60, 420), rng.randint(40, 300)
+        pngs.append(workload.make_png(8300 + it, w, h, ct=rng.choice([6, 6, 3]), ftype=rng.choice([1, 2, 3, 4, 5]),
+                                      noise=rng.choice([3, 24, workload.CFG4_NOISE]), enc="dynamic", idat_chunk=65536)[0])
+    monkeypatch.setenv("DEBIG_CHUNK_BYTES", "2048")
+    b = DevicePngBatch(pngs, device=gpu_device)
+    want = [oracle.decode_png(p) for p in pngs]
+    for group, lanes in ((21, 1), (5, 1), (4, 2), (2, 3)):
+        b.d_rgba.zero_()
+        b.launch_pipelined(group_images=group, lanes=lanes)
+        assert len(b.inflate.chunk_groups) == -(-21 // group)
+        res, ires = b.results()
+        for i, (good, px) in enumerate(want):
+            assert int(ires[i]["good"] and res[i]["good"]) == good == 1, (group, lanes, i)
+            assert np.array_equal(b.rgba(i), px), (group, lanes, i)
+    monkeypatch.delenv("DEBIG_CHUNK_BYTES", raising=False)
+
+
 def test_decode_png_in_chunk_tasks_with_the_aliasing_replay(gpu_device, oracle, monkeypatch):
     """decode_png's inflate forced through chunk tasks of 1 and 2 KiB (DEBIG_WAVES_PER_STREAM = 0x20,
     DEBIG_CHUNK_BYTES): RGBA and palette images of odd sizes, every filter type, several noise
