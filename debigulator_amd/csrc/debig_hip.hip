@@ -638,8 +638,12 @@ int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena
     // DEBIG_DEFILTER_WGS = 1 turns it off, 2 / 4 / 8 force G (measurements).
     {
         static std::once_flag once;
-        static uint32_t env_g = 0, env_w = 0;
+        static uint32_t env_g = 0, env_w = 0, env_blk = 0, env_px = 1;
         std::call_once(once, [] {
+            const char *ep = getenv("DEBIG_DEFILTER_PXSKEW"); /* 0: the group-skew step (measurements) */
+            if (ep && *ep) env_px = (uint32_t)strtoul(ep, nullptr, 0);
+            const char *eb = getenv("DEBIG_DEFILTER_BLK");
+            if (eb && *eb) env_blk = (uint32_t)strtoul(eb, nullptr, 0);
             const char *e = getenv("DEBIG_DEFILTER_WGS");
             if (e && *e) env_g = (uint32_t)strtoul(e, nullptr, 0);
             e = getenv("DEBIG_DEFILTER_WG_WAVES"); /* 2 | 4 | 8 wavefronts per workgroup in that mode (measurements) */
@@ -672,6 +676,15 @@ int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena
                                    (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n, g, gsync, 0u);
             else if (wpw == 2u)
                 hipLaunchKernelGGL((debig_png_defilter_kernel<2, 16, true>), dim3(n * g), dim3(128), 0, s,
+                                   (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n, g, gsync, 0u);
+            else if (env_blk == 32u) /* measurements: macro-steps per load phase (the share of the load phases in a band) */
+                hipLaunchKernelGGL((debig_png_defilter_kernel<4, 32, true>), dim3(n * g), dim3(256), 0, s,
+                                   (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n, g, gsync, 0u);
+            else if (env_blk == 8u)
+                hipLaunchKernelGGL((debig_png_defilter_kernel<4, 8, true>), dim3(n * g), dim3(256), 0, s,
+                                   (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n, g, gsync, 0u);
+            else if (env_px != 0u) /* lanes one PIXEL behind the row above (png_kernel.inc "PX"): the band below follows 32 macro-steps behind, not 79 */
+                hipLaunchKernelGGL((debig_png_defilter_kernel<4, 16, true, true>), dim3(n * g), dim3(256), 0, s,
                                    (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n, g, gsync, 0u);
             else
                 hipLaunchKernelGGL((debig_png_defilter_kernel<4, 16, true>), dim3(n * g), dim3(256), 0, s,

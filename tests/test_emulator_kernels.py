@@ -376,7 +376,7 @@ def test_defilter_workgroups_of_an_image_never_resident_together(emu):
     emu.emu_png_defilter_mwg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                          C.POINTER(C.c_uint32)]
     rng = np.random.default_rng(77)
-    shapes = [(6, 300, 64 * 9 + 5, None), (2, 90, 64 * 5 + 3, None), (6, 40, 700, 650), (6, 33, 40, None)]
+    shapes = [(6, 120, 64 * 17 + 5, None), (2, 90, 64 * 18 + 3, None), (6, 40, 700, 650), (6, 33, 40, None)]
     n = len(shapes)
     streams, exps = [], []
     for ct, w, h, bad in shapes:
@@ -403,7 +403,8 @@ def test_defilter_workgroups_of_an_image_never_resident_together(emu):
         ro += 4 * w * h + 64
     n_redo = C.c_uint32(0)
     assert emu.emu_png_defilter_mwg(sa.ctypes.data, rgba.ctypes.data, img, res, n, 4, C.byref(n_redo)) == 0
-    assert n_redo.value >= 2  # the images with more bands than one workgroup's wavefronts were given up first ...
+    assert n_redo.value >= 2  # the images with more bands than the image's 16 wavefronts (the ring wraps: a workgroup run earlier
+    # waits for one that has not started) were given up first ...
     for i, ((ct, w, h, bad), want) in enumerate(zip(shapes, exps)):
         if bad is not None:  # ... a real bad row is still a failed image
             assert (res[i].good, res[i].bad_row) == (0, bad)
@@ -411,6 +412,48 @@ def test_defilter_workgroups_of_an_image_never_resident_together(emu):
         assert res[i].good == 1, i  # ... and came back as the specification's pixels
         got = rgba[img[i].rgba_off: img[i].rgba_off + 4 * w * h].reshape(h, w, 4)
         assert np.array_equal(got, want), i
+
+
+def test_defilter_pixel_skew_step_one_workgroup(emu):
+    """debig_png_defilter_kernel<4, 16, true, true> ("PX": a lane runs one PIXEL behind the row above, the "up" pixels of a
+    macro-step come from the lane above in the same macro-step) with ONE workgroup per image, i.e. no wait across
+    workgroups: RGBA images of odd widths and heights (narrower than a wavefront's skew, one pixel wide, many bands),
+    every filter type per row, against the PNG specification's pixels; an RGB image beside them takes the group step."""
+    emu.emu_png_defilter_mwg.restype = C.c_int
+    emu.emu_png_defilter_mwg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                         C.POINTER(C.c_uint32)]
+    rng = np.random.default_rng(4242)
+    shapes = [(6, 301, 64 * 5 + 9), (6, 1, 70), (6, 2, 300), (6, 3, 5), (6, 64, 64), (6, 67, 129), (2, 90, 64 * 4 + 3),
+              (6, 1030, 66), (6, 5, 64 * 9 + 1)]
+    n = len(shapes)
+    streams, exps = [], []
+    for ct, w, h in shapes:
+        bpp = {6: 4, 2: 3}[ct]
+        st = rng.integers(0, 256, h * (w * bpp + 1), dtype=np.uint8)
+        st[:: w * bpp + 1] = rng.integers(0, 5, h)
+        want = _spec_defilter(st, w, h, bpp).reshape(h, w, bpp)
+        if ct == 2:
+            want = np.concatenate([want, np.full((h, w, 1), 255, np.uint8)], axis=2)
+        streams.append(st)
+        exps.append(want)
+    sa = np.zeros(sum(len(s) + 32 for s in streams) + 1024, dtype=np.uint8)
+    rgba = np.zeros(sum(4 * w * h + 64 for _, w, h in shapes), dtype=np.uint8)
+    img = (DebigPngImage * n)()
+    res = (DebigPngResult * n)()
+    so, ro = 1, 0
+    for i, ((ct, w, h), st) in enumerate(zip(shapes, streams)):
+        sa[so:so + len(st)] = st
+        img[i].stream_off, img[i].rgba_off, img[i].pal_off = so, ro, 0
+        img[i].width, img[i].height, img[i].color_type, img[i].asserts_off = w, h, ct, 0
+        so += len(st) + 30 + (i & 3)
+        ro += 4 * w * h + 64
+    n_redo = C.c_uint32(0)
+    assert emu.emu_png_defilter_mwg(sa.ctypes.data, rgba.ctypes.data, img, res, n, 1, C.byref(n_redo)) == 0
+    assert n_redo.value == 0
+    for i, ((ct, w, h), want) in enumerate(zip(shapes, exps)):
+        assert res[i].good == 1, i
+        got = rgba[img[i].rgba_off: img[i].rgba_off + 4 * w * h].reshape(h, w, 4)
+        assert np.array_equal(got, want), (i, shapes[i])
 
 
 def test_p3_rgb_replay_kernel_matches_reference_digest(emu):

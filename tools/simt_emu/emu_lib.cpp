@@ -231,7 +231,7 @@ extern "C" int emu_png_defilter_mwg(const void *streams_arena, void *rgba_arena,
                                     debig_png_result *results, uint32_t n, uint32_t g, uint32_t *n_redo)
 {
     uint32_t *gsync = (uint32_t *)calloc((size_t)n * PNG_GSYNC_STRIDE, sizeof(uint32_t));
-    EMU_LAUNCH((debig_png_defilter_kernel<4, 16, true>), n * g, 256, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images,
+    EMU_LAUNCH((debig_png_defilter_kernel<4, 16, true, true>), n * g, 256, (const uint8_t *)streams_arena, (uint8_t *)rgba_arena, images,
                results, n, g, gsync, 0u);
     uint32_t redo = 0;
     for (uint32_t i = 0; i < n; i++) redo += results[i].good == 0 && results[i].bad_row == PNG_ROW_REDO;
