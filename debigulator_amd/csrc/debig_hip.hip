@@ -651,11 +651,14 @@ int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena
         });
         // measured, 8192 x 8192 images (profiles/r03_defilter_wgs.txt): 32 images 43.6 -> 17.0 ms with 8 x 4
         // wavefronts, 64 images 46.6 -> 25.4 with 4 x 4, 128 images 54.6 -> 36.2 with 2 x 8
-        uint32_t g = n <= 32u ? 8u : n <= 64u ? 4u : n <= 128u ? 2u : 1u;
-        uint32_t wpw = n <= 64u ? 4u : 8u;
+        // with the pixel-skew step (round 4, profiles/r04_defilter_pixel_skew.txt: a band follows the one above 32 macro-steps
+        // behind, the image's wavefronts run back to back) more wavefronts per image pay again: 16 images 12.2 -> 8.4 ms with
+        // 16 x 4, 32 images 12.9 -> 12.1 with 8 x 8, 64 images 22.2 -> 19.0 with 4 x 8
+        uint32_t g = n <= 16u ? 16u : n <= 32u ? 8u : n <= 64u ? 4u : n <= 128u ? 2u : 1u;
+        uint32_t wpw = n <= 16u ? 4u : 8u;
         if (env_g) g = env_g;
         if (env_w == 2u || env_w == 4u || env_w == 8u) wpw = env_w;
-        if (g > 8u) g = 8u;
+        if (g > 16u) g = 16u;
         if (g * wpw > PNG_GSYNC_STRIDE - 16u) g = (PNG_GSYNC_STRIDE - 16u) / wpw; /* progress words per image */
         // all n * G workgroups must be resident TOGETHER (the bands of an image are a ring of dependencies): the limit
         // is what THIS device holds of THIS instantiation (its CU count x the runtime's occupancy answer), not a
@@ -671,7 +674,10 @@ int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena
             uint32_t *gsync = (uint32_t *)gw->ptr;
             hipError_t e = hipMemsetAsync(gsync, 0, (size_t)n * PNG_GSYNC_STRIDE * sizeof(uint32_t), s);
             if (e != hipSuccess) return (int)e;
-            if (wpw == 8u)
+            if (wpw == 8u && env_px != 0u)
+                hipLaunchKernelGGL((debig_png_defilter_kernel<8, 16, true, true>), dim3(n * g), dim3(512), 0, s,
+                                   (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n, g, gsync, 0u);
+            else if (wpw == 8u)
                 hipLaunchKernelGGL((debig_png_defilter_kernel<8, 16, true>), dim3(n * g), dim3(512), 0, s,
                                    (const uint8_t *)d_streams_arena, (uint8_t *)d_rgba_arena, d_images, d_results, n, g, gsync, 0u);
             else if (wpw == 2u)
