@@ -266,7 +266,12 @@ typedef struct debig_png_result {
 
 /* De-filter n inflated scanline streams into RGBA (device pointers, asynchronous on
  * hip_stream).  d_streams_arena must stay readable for 16 bytes past the end of every
- * stream (h * (w * bpp + 1) bytes): rows are fetched as aligned 16-byte pieces. */
+ * stream (h * (w * bpp + 1) bytes): rows are fetched as aligned 16-byte pieces.
+ * Up to 128 images: an image is spread over 16 / 8 / 4 / 2 workgroups (n <= 16 / 32 / 64 / 128; fewer when the device
+ * does not hold them all at once), the bands of 64 rows handed from wavefront to wavefront through memory; images whose
+ * workgroups turn out not to be resident together are decoded again by one workgroup inside the same call (never
+ * failed).  That mode uses a per-device scratch of progress words shared by the callers of the device (calls are
+ * ordered on it by events: such a call cannot be captured into a graph). */
 int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena,
                                  const debig_png_image *d_images, debig_png_result *d_results,
                                  uint32_t n, void *hip_stream);
