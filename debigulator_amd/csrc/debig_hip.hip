@@ -654,8 +654,10 @@ int debig_hip_png_defilter_batch(const void *d_streams_arena, void *d_rgba_arena
         // with the pixel-skew step (round 4, profiles/r04_defilter_pixel_skew.txt: a band follows the one above 32 macro-steps
         // behind, the image's wavefronts run back to back) more wavefronts per image pay again: 16 images 12.2 -> 8.4 ms with
         // 16 x 4, 32 images 12.9 -> 12.1 with 8 x 8, 64 images 22.2 -> 19.0 with 4 x 8
+        // (and with the predictor of a row selected by masks in the 4-wavefront kernel: 16 images 7.4 ms, 32 images 11.2 ms
+        // with 8 x 4 -- two wavefronts per SIMD prefer the branches and lose to it: 13.0)
         uint32_t g = n <= 16u ? 16u : n <= 32u ? 8u : n <= 64u ? 4u : n <= 128u ? 2u : 1u;
-        uint32_t wpw = n <= 16u ? 4u : 8u;
+        uint32_t wpw = n <= 32u ? 4u : 8u;
         if (env_g) g = env_g;
         if (env_w == 2u || env_w == 4u || env_w == 8u) wpw = env_w;
         if (g > 16u) g = 16u;
